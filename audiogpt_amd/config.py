@@ -1,0 +1,100 @@
+"""Shape source of truth for the Make-An-Audio hot path, as plain dicts.
+
+The reference keeps these in OmegaConf YAMLs (omegaconf is not available here):
+  * T2A      text_to_audio/Make_An_Audio/configs/text_to_audio/txt2audio_args.yaml:1-78
+  * I2A      text_to_audio/Make_An_Audio/configs/img_to_audio/img2audio_args.yaml:1-77
+  * Inpaint  text_to_audio/Make_An_Audio/configs/inpaint/txt2audio_args.yaml:1-68
+  * HiFi-GAN text_to_audio/Make_An_Audio/vocoder/logs/hifi_0127/args.yml:1-47,
+             NeuralSeq/egs/egs_bases/tts/vocoder/hifigan.yaml:3-10 (uic 512),
+             NeuralSeq/configs/tts/hifigan.yaml:3-10 (uic 128)
+"""
+from copy import deepcopy
+
+# ---------------------------------------------------------------- UNet variants
+UNET_T2A = dict(
+    variant="t2a",
+    in_channels=4, out_channels=4, model_channels=320,
+    attention_resolutions=(1, 2), num_res_blocks=2, channel_mult=(1, 2),
+    num_heads=8, num_head_channels=-1,
+    use_spatial_transformer=True, transformer_depth=1, context_dim=1024,
+    legacy=False, resblock_updown=False,
+    add_context_to_emb=False,          # custom_openaimodel.py:352-354 (I2A only)
+)
+
+UNET_I2A = dict(
+    variant="i2a",
+    in_channels=4, out_channels=4, model_channels=256,
+    attention_resolutions=(1, 2), num_res_blocks=2, channel_mult=(1, 2),
+    num_heads=-1, num_head_channels=32,
+    use_spatial_transformer=True, transformer_depth=1, context_dim=1024,
+    legacy=True, resblock_updown=False,
+    add_context_to_emb=True,
+)
+
+UNET_INPAINT = dict(
+    variant="inpaint",
+    in_channels=9, out_channels=4, model_channels=320,
+    attention_resolutions=(1, 2), num_res_blocks=2, channel_mult=(1, 2),
+    num_heads=8, num_head_channels=-1,
+    use_spatial_transformer=False, transformer_depth=1, context_dim=None,
+    legacy=True, resblock_updown=True,
+    add_context_to_emb=False,
+)
+
+# ---------------------------------------------------------------- VAE (AutoencoderKL ddconfig)
+VAE_DDCONFIG = dict(
+    double_z=True, z_channels=4, resolution=848, in_channels=1, out_ch=1,
+    ch=128, ch_mult=(1, 2, 2, 4), num_res_blocks=2, attn_resolutions=(106, 212),
+    embed_dim=4,
+)
+
+# ---------------------------------------------------------------- diffusion schedules
+LDM_T2A = dict(
+    unet=UNET_T2A, vae=VAE_DDCONFIG, timesteps=1000,
+    linear_start=0.00085, linear_end=0.0120,
+    conditioning_key="crossattn", latent_shape=(4, 10, 78), scale_factor=1.0,
+    sample_rate=16000, hop=256,
+)
+LDM_I2A = dict(
+    unet=UNET_I2A, vae=VAE_DDCONFIG, timesteps=1000,
+    linear_start=0.00085, linear_end=0.0120,
+    conditioning_key="crossattn", latent_shape=(4, 10, 78), scale_factor=1.0,
+    sample_rate=16000, hop=256,
+)
+LDM_INPAINT = dict(
+    unet=UNET_INPAINT, vae=VAE_DDCONFIG, timesteps=1000,
+    linear_start=0.0015, linear_end=0.0205,
+    conditioning_key="concat", latent_shape=(4, 10, 106), scale_factor=1.0,
+    sample_rate=16000, hop=256,
+)
+
+# ---------------------------------------------------------------- vocoders
+HIFIGAN_16K = dict(           # MAA/vocoder/logs/hifi_0127/args.yml
+    kind="hifigan", num_mels=80, upsample_initial_channel=512,
+    upsample_rates=(8, 8, 2, 2), upsample_kernel_sizes=(16, 16, 4, 4),
+    resblock="1", resblock_kernel_sizes=(3, 7, 11),
+    resblock_dilation_sizes=((1, 3, 5), (1, 3, 5), (1, 3, 5)),
+    sampling_rate=16000,
+)
+HIFIGAN_NS_512 = dict(HIFIGAN_16K, sampling_rate=22050)                    # egs_bases/tts/vocoder/hifigan.yaml
+HIFIGAN_NS_128 = dict(HIFIGAN_16K, sampling_rate=22050, upsample_initial_channel=128)  # configs/tts/hifigan.yaml
+
+# BigVGAN's args.yml (vocoder/logs/bigv16k53w) does not ship with the reference
+# (SURVEY.md section 0.3); these are the generator defaults it is exercised with here.
+BIGVGAN_16K = dict(
+    HIFIGAN_16K, kind="bigvgan", activation="snakebeta", snake_logscale=True,
+)
+
+
+def small(cfg, **over):
+    """A reduced copy of a config for quick tests."""
+    c = deepcopy(cfg)
+    c.update(over)
+    return c
+
+
+def hop_size(voc_cfg):
+    h = 1
+    for u in voc_cfg["upsample_rates"]:
+        h *= u
+    return h

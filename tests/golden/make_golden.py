@@ -1,0 +1,239 @@
+"""Generate golden vectors from the REFERENCE's own modules (run in the build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference; writes tests/golden/*.npz
+
+The reference ships no tests or fixtures for this path, so the oracle is
+pinned against the reference modules themselves: each case builds the reference module from
+/root/reference, loads the seeded weights produced by `audiogpt_amd.weights` (reference key layout,
+`strict=True`), runs it on seeded inputs on CPU fp32 and stores inputs + outputs.  Weights are NOT
+stored (they are regenerated from the seed); `manifest.json` records every state_dict key/shape of
+the reference modules so the factory's key layout is pinned too.
+
+Import shims: `omegaconf` stub (bigvgan/models.py:17, openaimodel.py:474),
+`scipy.signal.kaiser` shim and a `utils.hparams` stub for NeuralSeq's hifigan.py import chain.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+MAA = os.path.join(REF, "text_to_audio", "Make_An_Audio")
+NS = os.path.join(REF, "NeuralSeq")
+
+from audiogpt_amd import config as C          # noqa: E402
+from audiogpt_amd import weights as WT         # noqa: E402
+
+
+def _install_shims():
+    om = types.ModuleType("omegaconf")
+    om.OmegaConf = type("OmegaConf", (), {"load": staticmethod(lambda p: None)})
+    lc = types.ModuleType("omegaconf.listconfig")
+    lc.ListConfig = type("ListConfig", (list,), {})
+    om.listconfig = lc
+    sys.modules.setdefault("omegaconf", om)
+    sys.modules.setdefault("omegaconf.listconfig", lc)
+    import scipy.signal
+    if not hasattr(scipy.signal, "kaiser"):
+        scipy.signal.kaiser = scipy.signal.windows.kaiser
+    sys.path.insert(0, MAA)
+
+
+def _ns_generator_cls():
+    """Load NeuralSeq/modules/hifigan/hifigan.py without its parallel_wavegan import chain."""
+    import importlib.util
+    for name in ("modules", "modules.parallel_wavegan", "modules.parallel_wavegan.layers",
+                 "modules.parallel_wavegan.models", "modules.parallel_wavegan.models.source"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["modules.parallel_wavegan.layers"].UpsampleNetwork = object
+    sys.modules["modules.parallel_wavegan.layers"].ConvInUpsampleNetwork = object
+    sys.modules["modules.parallel_wavegan.models.source"].SourceModuleHnNSF = object
+    spec = importlib.util.spec_from_file_location("ns_hifigan", os.path.join(NS, "modules/hifigan/hifigan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.HifiGanGenerator
+
+
+def _manifest(module):
+    return {k: list(v.shape) for k, v in module.state_dict().items()}
+
+
+def _cond(n, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    c = torch.randn(n, L, 1024, generator=g)
+    return torch.nn.functional.layer_norm(c, (1024,))
+
+
+def unet_case(name, cfg, H, W, ctx_len, manifest, n=2, seed=0):
+    if cfg["variant"] == "i2a":
+        from ldm.modules.diffusionmodules.custom_openaimodel import UNetModel
+        kw = dict(use_context_project=False)
+    else:
+        from ldm.modules.diffusionmodules.openaimodel import UNetModel
+        kw = dict(legacy=cfg["legacy"])
+    m = UNetModel(image_size=32, in_channels=cfg["in_channels"], out_channels=cfg["out_channels"],
+                  model_channels=cfg["model_channels"], attention_resolutions=list(cfg["attention_resolutions"]),
+                  num_res_blocks=cfg["num_res_blocks"], channel_mult=list(cfg["channel_mult"]),
+                  num_heads=cfg["num_heads"], num_head_channels=cfg["num_head_channels"],
+                  use_spatial_transformer=cfg["use_spatial_transformer"],
+                  transformer_depth=cfg["transformer_depth"], context_dim=cfg["context_dim"],
+                  resblock_updown=cfg["resblock_updown"], use_checkpoint=True, **kw).eval()
+    manifest[name] = _manifest(m)
+    sd = WT.make_unet_state_dict(cfg, seed=seed)
+    m.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(100 + seed)
+    x = torch.randn(n, cfg["in_channels"], H, W, generator=g)
+    t = torch.tensor([981, 11][:n], dtype=torch.long)
+    ctx = _cond(n, ctx_len, 1234) if cfg["context_dim"] else None
+    with torch.no_grad():
+        y = m(x, t, context=ctx)
+    out = dict(x=x.numpy(), t=t.numpy(), y=y.numpy())
+    if ctx is not None:
+        out["context"] = ctx.numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "out std", float(y.std()), "absmax", float(y.abs().max()))
+    return m
+
+
+def ddim_case(name, unet, cfg, manifest, S=10, scale=1.5, seed=0):
+    """DDIMSampler driven through a minimal model shim."""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+
+    class Shim:
+        def __init__(self, ldm):
+            betas = make_beta_schedule("linear", ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+            ac = np.cumprod(1.0 - betas, axis=0)
+            self.num_timesteps = ldm["timesteps"]
+            self.betas = torch.tensor(betas, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+            self.device = torch.device("cpu")
+
+        def apply_model(self, x, t, c):          # DiffusionWrapper crossattn path (ddpm.py:1407-1409)
+            return unet(x, t, context=c)
+
+    ldm = C.LDM_T2A
+    sampler = DDIMSampler(Shim(ldm))
+    sampler.device = torch.device("cpu")
+    x_T = torch.from_numpy(np.random.RandomState(55).randn(1, 4, 10, 78)).float()   # audio-chatgpt.py:160-162
+    c, uc = _cond(1, 77, 1234), _cond(1, 77, 1235)
+    torch.manual_seed(0)
+    with torch.no_grad():
+        z, inter = sampler.sample(S=S, conditioning=c, batch_size=1, shape=[4, 10, 78], verbose=False,
+                                  unconditional_guidance_scale=scale, unconditional_conditioning=uc, x_T=x_T,
+                                  log_every_t=1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), x_T=x_T.numpy(), c=c.numpy(), uc=uc.numpy(),
+                        z=z.numpy(), ddim_timesteps=np.asarray(sampler.ddim_timesteps),
+                        ddim_alphas=np.asarray(sampler.ddim_alphas), ddim_alphas_prev=np.asarray(sampler.ddim_alphas_prev),
+                        x_inter=np.stack([t.numpy() for t in inter["x_inter"]]), S=S, scale=scale)
+    print(name, "z std", float(z.std()))
+    return z
+
+
+def vae_case(name, dd, manifest, z=None, seed=1):
+    from ldm.modules.diffusionmodules.model import Decoder, Encoder
+    kw = dict(ch=dd["ch"], out_ch=dd["out_ch"], ch_mult=tuple(dd["ch_mult"]), num_res_blocks=dd["num_res_blocks"],
+              attn_resolutions=list(dd["attn_resolutions"]), in_channels=dd["in_channels"],
+              resolution=dd["resolution"], z_channels=dd["z_channels"], double_z=dd["double_z"])
+    dec, enc = Decoder(**kw).eval(), Encoder(**kw).eval()
+    manifest[name + ".decoder"] = _manifest(dec)
+    manifest[name + ".encoder"] = _manifest(enc)
+    sd = WT.make_vae_state_dict(dd, seed=seed)
+    dec.load_state_dict(WT.strip_prefix(sd, "decoder."), strict=True)
+    enc.load_state_dict(WT.strip_prefix(sd, "encoder."), strict=True)
+    pq = torch.nn.Conv2d(dd["embed_dim"], dd["z_channels"], 1)
+    qc = torch.nn.Conv2d(2 * dd["z_channels"], 2 * dd["embed_dim"], 1)
+    pq.load_state_dict(WT.strip_prefix(sd, "post_quant_conv."))
+    qc.load_state_dict(WT.strip_prefix(sd, "quant_conv."))
+    if z is None:
+        g = torch.Generator().manual_seed(200 + seed)
+        z = torch.randn(1, 4, 10, 78, generator=g)
+    g = torch.Generator().manual_seed(300 + seed)
+    mel_in = torch.rand(1, 1, 80, 848 if dd["resolution"] == 848 else 64, generator=g) * 2 - 1
+    with torch.no_grad():
+        mel = dec(pq(z))                  # autoencoder.py:351-354
+        moments = qc(enc(mel_in))         # autoencoder.py:345-349
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), z=z.numpy(), mel=mel.numpy(),
+                        mel_in=mel_in.numpy(), moments=moments.numpy())
+    print(name, "mel std", float(mel.std()), "moments std", float(moments.std()))
+    return mel
+
+
+def hifigan_case(name, cfg, T, manifest, B=1, seed=2, mel=None):
+    from argparse import Namespace
+    from vocoder.hifigan.modules import Generator
+    gen = Generator(Namespace(**{k: (list(map(list, v)) if k == "resblock_dilation_sizes" else
+                                     (list(v) if isinstance(v, tuple) else v)) for k, v in cfg.items()})).eval()
+    manifest[name + ".maa"] = _manifest(gen)
+    sd = WT.make_vocoder_state_dict(cfg, seed=seed)
+    gen.load_state_dict(sd, strict=True)
+    if mel is None:
+        g = torch.Generator().manual_seed(7)
+        mel = torch.clamp(torch.randn(B, 80, T, generator=g) * 1.5 - 2.25, -6.0, 1.5)
+    with torch.no_grad():
+        wav = gen(mel)
+    # the NeuralSeq generator must agree on the same weights (same graph, hifigan.py:144-169)
+    NSGen = _ns_generator_cls()
+    h = {k: (list(map(list, v)) if k == "resblock_dilation_sizes" else (list(v) if isinstance(v, tuple) else v))
+         for k, v in cfg.items()}
+    h["use_pitch_embed"] = False
+    ns = NSGen(h).eval()
+    manifest[name + ".ns"] = _manifest(ns)
+    ns.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        wav_ns = ns(mel)
+    assert torch.equal(wav, wav_ns), "MAA Generator and NeuralSeq HifiGanGenerator disagree"
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), mel=mel.numpy(), wav=wav.numpy())
+    print(name, "wav std", float(wav.std()), "absmax", float(wav.abs().max()))
+    return wav
+
+
+def bigvgan_case(name, cfg, T, manifest, seed=3):
+    from argparse import Namespace
+    from vocoder.bigvgan.models import BigVGAN
+    gen = BigVGAN(Namespace(**{k: (list(map(list, v)) if k == "resblock_dilation_sizes" else
+                                   (list(v) if isinstance(v, tuple) else v)) for k, v in cfg.items()})).eval()
+    manifest[name] = _manifest(gen)
+    sd = WT.make_vocoder_state_dict(cfg, seed=seed)
+    missing, unexpected = gen.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.endswith("filter") for k in missing), missing      # registered FIR buffers only
+    filt = gen.activation_post.upsample.filter.reshape(-1).numpy()
+    g = torch.Generator().manual_seed(8)
+    mel = torch.clamp(torch.randn(1, 80, T, generator=g) * 1.5 - 2.25, -6.0, 1.5)
+    with torch.no_grad():
+        wav = gen(mel)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), mel=mel.numpy(), wav=wav.numpy(), filter=filt)
+    print(name, "wav std", float(wav.std()), "absmax", float(wav.abs().max()))
+
+
+def main():
+    torch.set_num_threads(8)
+    _install_shims()
+    manifest = {}
+    unet = unet_case("unet_t2a", C.UNET_T2A, 10, 78, 77, manifest)
+    z = ddim_case("ddim_t2a_s10", unet, C.UNET_T2A, manifest)
+    unet_case("unet_i2a", C.UNET_I2A, 10, 78, 1, manifest, seed=4)
+    unet_case("unet_inpaint", C.UNET_INPAINT, 10, 106, 0, manifest, n=1, seed=5)
+    mel = vae_case("vae", C.VAE_DDCONFIG, manifest, z=z)
+    # plumbing config 1 end to end: clamp((x+1)/2, 0, 1) -> vocoder (audio-chatgpt.py:176-181)
+    spec = torch.clamp((mel + 1.0) / 2.0, 0.0, 1.0)[:, 0]
+    hifigan_case("hifigan_16k_t2a", C.HIFIGAN_16K, 624, manifest, mel=spec)
+    hifigan_case("hifigan_ns512", C.HIFIGAN_NS_512, 64, manifest, B=2)
+    hifigan_case("hifigan_ns128", C.HIFIGAN_NS_128, 96, manifest, B=2)
+    bigvgan_case("bigvgan_16k", C.BIGVGAN_16K, 48, manifest)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    print("torch", torch.__version__)
+
+
+if __name__ == "__main__":
+    main()

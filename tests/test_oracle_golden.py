@@ -1,0 +1,127 @@
+"""Pin the CPU oracle against golden vectors produced by the reference's own modules
+(tests/golden/make_golden.py).  Tolerances are fp32 reduction-order noise."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from audiogpt_amd import config as C
+from audiogpt_amd import weights as WT
+from oracle import ddim as O_ddim
+from oracle import unet as O_unet
+from oracle import vae as O_vae
+from oracle import vocoder as O_voc
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _close(a, b, atol, name=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b).max()
+    assert err <= atol, f"{name}: max abs err {err:.3e} > {atol:.1e} (ref absmax {np.abs(b).max():.3e})"
+
+
+@pytest.mark.parametrize("name,cfg,seed", [("unet_t2a", C.UNET_T2A, 0), ("unet_i2a", C.UNET_I2A, 4),
+                                           ("unet_inpaint", C.UNET_INPAINT, 5)])
+def test_unet_matches_reference(golden, name, cfg, seed):
+    g = golden(name)
+    sd = WT.make_unet_state_dict(cfg, seed=seed)
+    ctx = torch.from_numpy(g["context"]) if "context" in g else None
+    with torch.no_grad():
+        y = O_unet.unet_forward(sd, cfg, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), ctx)
+    _close(y.numpy(), g["y"], 2e-5, name)
+
+
+def test_state_dict_layout_matches_reference_manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        man = json.load(f)
+    cases = {
+        "unet_t2a": WT.make_unet_state_dict(C.UNET_T2A),
+        "unet_i2a": WT.make_unet_state_dict(C.UNET_I2A),
+        "unet_inpaint": WT.make_unet_state_dict(C.UNET_INPAINT),
+        "hifigan_16k_t2a.maa": WT.make_vocoder_state_dict(C.HIFIGAN_16K),
+        "hifigan_ns128.ns": WT.make_vocoder_state_dict(C.HIFIGAN_NS_128),
+    }
+    vae = WT.make_vae_state_dict(C.VAE_DDCONFIG)
+    cases["vae.decoder"] = WT.strip_prefix(vae, "decoder.")
+    cases["vae.encoder"] = WT.strip_prefix(vae, "encoder.")
+    for name, sd in cases.items():
+        ours = {k: list(v.shape) for k, v in sd.items()}
+        assert ours == man[name], name
+    big = {k: list(v.shape) for k, v in WT.make_vocoder_state_dict(C.BIGVGAN_16K).items()}
+    ref_big = {k: v for k, v in man["bigvgan_16k"].items() if not k.endswith("filter")}
+    assert big == ref_big
+
+
+def test_ddim_schedule_tables(golden):
+    g = golden("ddim_t2a_s10")
+    ac = O_ddim.alphas_cumprod(1000, C.LDM_T2A["linear_start"], C.LDM_T2A["linear_end"])
+    steps = O_ddim.ddim_timesteps(10)
+    assert steps.tolist() == g["ddim_timesteps"].tolist() == [1 + 100 * i for i in range(10)]
+    a, ap, sig, som = O_ddim.ddim_tables(ac, steps)
+    assert np.array_equal(a.numpy(), g["ddim_alphas"].astype(np.float32))
+    assert np.array_equal(ap.numpy(), g["ddim_alphas_prev"].astype(np.float32))
+    assert float(sig.abs().max()) == 0.0
+    assert O_ddim.ddim_timesteps(100)[:3].tolist() == [1, 11, 21]
+
+
+def test_ddim_10_steps_matches_reference(golden):
+    g = golden("ddim_t2a_s10")
+    cfg = C.UNET_T2A
+    sd = WT.make_unet_state_dict(cfg, seed=0)
+    ac = O_ddim.alphas_cumprod(1000, C.LDM_T2A["linear_start"], C.LDM_T2A["linear_end"])
+    trace = []
+    with torch.no_grad():
+        z = O_ddim.ddim_sample(lambda x, t, c: O_unet.unet_forward(sd, cfg, x, t, c), ac, int(g["S"]),
+                               torch.from_numpy(g["x_T"]), torch.from_numpy(g["c"]), torch.from_numpy(g["uc"]),
+                               scale=float(g["scale"]), trace=trace)
+    # x_inter[0] is x_T, then one entry per step (log_every_t=1)
+    for i, x in enumerate(trace):
+        _close(x.numpy(), g["x_inter"][i + 1], 2e-4, f"step {i}")
+    _close(z.numpy(), g["z"], 2e-4, "z")
+
+
+def test_vae_matches_reference(golden):
+    g = golden("vae")
+    dd = C.VAE_DDCONFIG
+    sd = WT.make_vae_state_dict(dd, seed=1)
+    with torch.no_grad():
+        mel = O_vae.decode_first_stage(sd, dd, torch.from_numpy(g["z"]), 1.0)
+        mean, logvar = O_vae.encode_moments(sd, dd, torch.from_numpy(g["mel_in"]))
+    _close(mel.numpy(), g["mel"], 5e-5, "mel")
+    mom = torch.from_numpy(g["moments"])
+    m_ref, lv_ref = torch.chunk(mom, 2, dim=1)
+    _close(mean.numpy(), m_ref.numpy(), 5e-5, "mean")
+    _close(logvar.numpy(), torch.clamp(lv_ref, -30.0, 20.0).numpy(), 5e-5, "logvar")
+
+
+@pytest.mark.parametrize("name,cfg", [("hifigan_16k_t2a", C.HIFIGAN_16K), ("hifigan_ns512", C.HIFIGAN_NS_512),
+                                      ("hifigan_ns128", C.HIFIGAN_NS_128)])
+def test_hifigan_matches_reference(golden, name, cfg):
+    g = golden(name)
+    sd = O_voc.fold_weight_norm(WT.make_vocoder_state_dict(cfg, seed=2))
+    with torch.no_grad():
+        wav = O_voc.hifigan_forward(sd, cfg, torch.from_numpy(g["mel"]))
+    _close(wav.numpy(), g["wav"], 2e-6, name)
+
+
+def test_bigvgan_matches_reference(golden):
+    g = golden("bigvgan_16k")
+    cfg = C.BIGVGAN_16K
+    filt = O_voc.kaiser_sinc_filter1d(0.25, 0.3, 12)
+    _close(filt.numpy(), g["filter"], 1e-7, "kaiser-sinc filter")
+    sd = O_voc.fold_weight_norm(WT.make_vocoder_state_dict(cfg, seed=3))
+    with torch.no_grad():
+        wav = O_voc.bigvgan_forward(sd, cfg, torch.from_numpy(g["mel"]))
+    _close(wav.numpy(), g["wav"], 5e-6, "bigvgan")
+
+
+def test_weight_factory_has_no_dead_tensors():
+    """zero_module tensors are re-randomised: nothing is all-zero."""
+    for sd in (WT.make_unet_state_dict(C.UNET_T2A), WT.make_vae_state_dict(C.VAE_DDCONFIG),
+               WT.make_vocoder_state_dict(C.HIFIGAN_16K)):
+        for k, v in sd.items():
+            assert float(v.abs().max()) > 0, k
