@@ -1,0 +1,324 @@
+"""Handle objects over the C ABI: context, UNet, VAE, vocoder, and the single-operator entry points.
+
+torch is used for device buffers and the stream only; every computation below happens inside
+libaudiogpt_mi355x.so.  All tensors at this boundary are fp32, contiguous, in the reference's layouts.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _f32(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class Context:
+    """One (device, stream) execution context.  Calls are serialised with a lock, like the reference's
+    non re-entrant sampler (ddim.py:27-56)."""
+
+    def __init__(self, device="cuda:0", stream=None):
+        self.lib = L.load()
+        if not torch.cuda.is_available():
+            raise L.MaaError("no MI355X visible: the HIP backend has no CPU fallback")
+        self.device = torch.device(device)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        torch.cuda.set_device(idx)
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._stream = s
+        h = C.c_void_p()
+        L.check(self.lib.maa_ctx_create(idx, C.c_void_p(s.cuda_stream), C.byref(h)))
+        self.h = h
+        self.lock = threading.RLock()
+
+    def synchronize(self):
+        L.check(self.lib.maa_ctx_synchronize(self.h))
+
+    def workspace_bytes(self):
+        n = C.c_size_t()
+        L.check(self.lib.maa_ctx_workspace_bytes(self.h, C.byref(n)))
+        return n.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.maa_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- single operators (parity tests / kernel profiling) -------------------------------------
+    def op_linear(self, a, w, b=None, geglu=False):
+        a = _f32(a, self.device)
+        M, K = a.shape
+        N = w.shape[0]
+        wt, wp = L.host_f32(w)
+        bt, bp = L.host_f32(b) if b is not None else (None, None)
+        y = torch.empty(M, N // 2 if geglu else N, device=self.device)
+        L.check(self.lib.maa_op_linear(self.h, L.dptr(a), M, K, wp, bp, N, int(geglu), L.dptr(y)))
+        return y
+
+    def op_conv(self, x, w, b=None, stride=1, pad=0, dil=1, up=False, leaky=0.0, out_hw=None):
+        """x [B,Cin,H,W]; w [Cout,Cin,KH,KW]; returns [B,Cout,Ho,Wo]."""
+        x = _f32(x, self.device)
+        B, Cin, H, W = x.shape
+        Cout, _, KH, KW = w.shape
+        if out_hw is None:
+            He, We = (2 * H, 2 * W) if up else (H, W)
+            ph = pad if KH > 1 else 0
+            Ho = (He + 2 * ph - dil * (KH - 1) - 1) // stride + 1
+            Wo = (We + 2 * pad - dil * (KW - 1) - 1) // stride + 1
+        else:
+            Ho, Wo = out_hw
+        wt, wp = L.host_f32(w)
+        bt, bp = L.host_f32(b) if b is not None else (None, None)
+        y = torch.empty(B, Cout, Ho, Wo, device=self.device)
+        L.check(self.lib.maa_op_conv(self.h, L.dptr(x), B, Cin, H, W, wp, bp, Cout, KH, KW, stride, pad, dil,
+                                     int(up), float(leaky), L.dptr(y), Ho, Wo))
+        return y
+
+    def op_groupnorm(self, x, gamma, beta, eps, silu=False):
+        x = _f32(x, self.device)
+        B, Cc = x.shape[:2]
+        HW = int(np.prod(x.shape[2:]))
+        gt, gp = L.host_f32(gamma)
+        bt, bp = L.host_f32(beta)
+        y = torch.empty_like(x)
+        L.check(self.lib.maa_op_groupnorm(self.h, L.dptr(x), B, Cc, HW, gp, bp, float(eps), int(silu), L.dptr(y)))
+        return y
+
+    def op_layernorm(self, x, gamma, beta, eps=1e-5):
+        x = _f32(x, self.device)
+        rows, Cc = x.reshape(-1, x.shape[-1]).shape
+        gt, gp = L.host_f32(gamma)
+        bt, bp = L.host_f32(beta)
+        y = torch.empty_like(x)
+        L.check(self.lib.maa_op_layernorm(self.h, L.dptr(x), rows, Cc, gp, bp, float(eps), L.dptr(y)))
+        return y
+
+    def op_attention(self, q, k, v, heads, alpha):
+        q, k, v = _f32(q, self.device), _f32(k, self.device), _f32(v, self.device)
+        B, Nq, Cc = q.shape
+        Nk = k.shape[1]
+        y = torch.empty_like(q)
+        L.check(self.lib.maa_op_attention(self.h, L.dptr(q), L.dptr(k), L.dptr(v), B, heads, Cc // heads, Nq, Nk,
+                                          float(alpha), L.dptr(y)))
+        return y
+
+    def op_conv_transpose1d(self, x, w, b, stride, leaky=0.0):
+        x = _f32(x, self.device)
+        B, Cin, Ln = x.shape
+        _, Cout, k = w.shape
+        wt, wp = L.host_f32(w)
+        bt, bp = L.host_f32(b)
+        y = torch.empty(B, Cout, Ln * stride, device=self.device)
+        L.check(self.lib.maa_op_conv_transpose1d(self.h, L.dptr(x), B, Cin, Ln, wp, bp, Cout, k, stride, float(leaky),
+                                                 L.dptr(y)))
+        return y
+
+    def op_snake_aa(self, x, alpha, beta, logscale):
+        x = _f32(x, self.device)
+        B, Cc, Ln = x.shape
+        at, ap = L.host_f32(alpha)
+        bt, bp = L.host_f32(beta)
+        y = torch.empty_like(x)
+        L.check(self.lib.maa_op_snake_aa(self.h, L.dptr(x), B, Cc, Ln, ap, bp, int(logscale), L.dptr(y)))
+        return y
+
+
+def _fill(arr, values):
+    for i, v in enumerate(values):
+        arr[i] = int(v)
+    return len(values)
+
+
+class UNet:
+    """maa_unet handle: replaces instantiate_from_config(unet_config) + load_state_dict."""
+
+    def __init__(self, ctx, cfg, state_dict):
+        self.ctx, self.cfg = ctx, cfg
+        c = L.maa_unet_config()
+        c.in_channels, c.out_channels, c.model_channels = cfg["in_channels"], cfg["out_channels"], cfg["model_channels"]
+        c.num_res_blocks = cfg["num_res_blocks"]
+        c.n_channel_mult = _fill(c.channel_mult, cfg["channel_mult"])
+        c.n_attention_resolutions = _fill(c.attention_resolutions, cfg["attention_resolutions"])
+        c.num_heads, c.num_head_channels = cfg["num_heads"], cfg["num_head_channels"]
+        c.use_spatial_transformer = int(cfg["use_spatial_transformer"])
+        c.transformer_depth = cfg.get("transformer_depth", 1)
+        c.context_dim = cfg["context_dim"] or 0
+        c.legacy, c.resblock_updown = int(cfg["legacy"]), int(cfg["resblock_updown"])
+        c.add_context_to_emb = int(cfg.get("add_context_to_emb", False))
+        arr, n, keep = L.tensor_list(state_dict)
+        h = C.c_void_p()
+        with ctx.lock:
+            L.check(ctx.lib.maa_unet_create(ctx.h, C.byref(c), arr, n, C.byref(h)))
+        self.h = h
+        self._context = None
+
+    def set_context(self, context):
+        """context [B, L, context_dim] on the device; K/V projections are cached for the next forwards."""
+        context = _f32(context, self.ctx.device)
+        self._context = context                 # keep alive: the I2A variant re-reads it every forward
+        B, Ln, _ = context.shape
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_unet_set_context(self.ctx.h, self.h, L.dptr(context), B, Ln))
+
+    def forward(self, x, t, context=None):
+        """UNetModel.forward(x, timesteps, context) (openaimodel.py:711-744)."""
+        if context is not None:
+            self.set_context(context)
+        x = _f32(x, self.ctx.device)
+        tf = t.to(device=self.ctx.device, dtype=torch.float32).contiguous()
+        B, _, H, W = x.shape
+        out = torch.empty(B, self.cfg["out_channels"], H, W, device=self.ctx.device)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_unet_forward(self.ctx.h, self.h, L.dptr(x), L.dptr(tf), B, H, W, L.dptr(out)))
+        return out
+
+    __call__ = forward
+
+    def ddim_sample(self, x_T, timesteps, alphas, alphas_prev, cond=None, uncond=None, scale=1.0, concat=None,
+                    use_graph=True):
+        """Whole DDIM trajectory on the device (ddim.py:118-225, eta = 0).  Returns x_0."""
+        dev = self.ctx.device
+        x = _f32(x_T, dev).clone()
+        B, Cc, H, W = x.shape
+        a = L.maa_ddim_args()
+        ts = np.ascontiguousarray(np.asarray(timesteps), dtype=np.int32)
+        al = np.ascontiguousarray(np.asarray(alphas), dtype=np.float32)
+        ap = np.ascontiguousarray(np.asarray(alphas_prev), dtype=np.float32)
+        a.S, a.B, a.C, a.H, a.W = len(ts), B, Cc, H, W
+        a.scale = float(scale)
+        keep = []
+        if cond is not None:
+            cond = _f32(cond, dev)
+            keep.append(cond)
+            a.d_cond = cond.data_ptr()
+            a.L = cond.shape[1]
+        if uncond is not None:
+            uncond = _f32(uncond, dev)
+            keep.append(uncond)
+            a.d_uncond = uncond.data_ptr()
+        if concat is not None:
+            concat = _f32(concat, dev)
+            keep.append(concat)
+            a.d_concat = concat.data_ptr()
+            a.Cc = concat.shape[1]
+        a.h_timesteps = ts.ctypes.data_as(C.POINTER(C.c_int32))
+        a.h_alphas = al.ctypes.data_as(C.POINTER(C.c_float))
+        a.h_alphas_prev = ap.ctypes.data_as(C.POINTER(C.c_float))
+        a.use_graph = int(use_graph)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_ddim_sample(self.ctx.h, self.h, C.byref(a), L.dptr(x)))
+        return x
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.maa_unet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class VAE:
+    def __init__(self, ctx, dd, state_dict):
+        self.ctx, self.dd = ctx, dd
+        c = L.maa_vae_config()
+        c.ch, c.out_ch, c.in_channels, c.z_channels = dd["ch"], dd["out_ch"], dd["in_channels"], dd["z_channels"]
+        c.embed_dim, c.resolution, c.num_res_blocks = dd["embed_dim"], dd["resolution"], dd["num_res_blocks"]
+        c.double_z = int(dd["double_z"])
+        c.n_ch_mult = _fill(c.ch_mult, dd["ch_mult"])
+        c.n_attn_resolutions = _fill(c.attn_resolutions, dd["attn_resolutions"])
+        arr, n, keep = L.tensor_list(state_dict)
+        h = C.c_void_p()
+        with ctx.lock:
+            L.check(ctx.lib.maa_vae_create(ctx.h, C.byref(c), arr, n, C.byref(h)))
+        self.h = h
+
+    def decode(self, z, scale_factor=1.0):
+        """decode_first_stage (ddpm_audio.py:352-359): z [B,4,h,w] -> mel [B,1,8h,8w]."""
+        z = _f32(z, self.ctx.device)
+        B, _, h, w = z.shape
+        f = 2 ** (len(self.dd["ch_mult"]) - 1)
+        mel = torch.empty(B, self.dd["out_ch"], h * f, w * f, device=self.ctx.device)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_vae_decode(self.ctx.h, self.h, L.dptr(z), B, h, w, 1.0 / float(scale_factor),
+                                                L.dptr(mel)))
+        return mel
+
+    def encode_moments(self, mel):
+        """AutoencoderKL.encode moments (autoencoder.py:345-349): mel [B,1,H,W] -> [B, 2*embed, H/8, W/8]."""
+        mel = _f32(mel, self.ctx.device)
+        B, _, H, W = mel.shape
+        f = 2 ** (len(self.dd["ch_mult"]) - 1)
+        out = torch.empty(B, 2 * self.dd["embed_dim"], H // f, W // f, device=self.ctx.device)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_vae_encode_moments(self.ctx.h, self.h, L.dptr(mel), B, H, W, L.dptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.maa_vae_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Vocoder:
+    def __init__(self, ctx, cfg, state_dict):
+        self.ctx, self.cfg = ctx, cfg
+        c = L.maa_vocoder_config()
+        c.kind = 1 if cfg["kind"] == "bigvgan" else 0
+        c.num_mels, c.upsample_initial_channel = cfg["num_mels"], cfg["upsample_initial_channel"]
+        c.n_upsamples = _fill(c.upsample_rates, cfg["upsample_rates"])
+        _fill(c.upsample_kernel_sizes, cfg["upsample_kernel_sizes"])
+        c.n_kernels = _fill(c.resblock_kernel_sizes, cfg["resblock_kernel_sizes"])
+        c.n_dilations = len(cfg["resblock_dilation_sizes"][0])
+        for j, ds in enumerate(cfg["resblock_dilation_sizes"]):
+            for m, d in enumerate(ds):
+                c.resblock_dilation_sizes[j][m] = int(d)
+        c.snake_beta = int(cfg.get("activation", "") == "snakebeta")
+        c.snake_logscale = int(cfg.get("snake_logscale", False))
+        arr, n, keep = L.tensor_list(state_dict)
+        h = C.c_void_p()
+        with ctx.lock:
+            L.check(ctx.lib.maa_vocoder_create(ctx.h, C.byref(c), arr, n, C.byref(h)))
+        self.h = h
+        self.hop = int(np.prod(cfg["upsample_rates"]))
+
+    def forward(self, mel):
+        """mel [B, num_mels, T] -> wav [B, 1, T*hop] (HifiGanGenerator.forward, hifigan.py:144-169)."""
+        mel = _f32(mel, self.ctx.device)
+        B, _, T = mel.shape
+        wav = torch.empty(B, 1, T * self.hop, device=self.ctx.device)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_vocoder_forward(self.ctx.h, self.h, L.dptr(mel), B, T, L.dptr(wav)))
+        return wav
+
+    __call__ = forward
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.maa_vocoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,407 @@
+// extern "C" surface of libaudiogpt_mi355x (include/maa.h): argument checking, handle ownership and the
+// exception -> status translation.  No C++ type or exception crosses this file's boundary.
+#include "models.h"
+
+#include <cstring>
+#include <memory>
+
+namespace maa {
+const char* last_error_cstr();
+}
+
+struct maa_ctx {
+    maa::Ctx c;
+};
+struct maa_unet {
+    std::unique_ptr<maa::UNet> m;
+};
+struct maa_vae {
+    std::unique_ptr<maa::VAE> m;
+};
+struct maa_vocoder {
+    std::unique_ptr<maa::Vocoder> m;
+};
+
+namespace {
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        f();
+        return MAA_OK;
+    } catch (const maa::Error& e) {
+        maa::set_last_error(e.what());
+        const bool hip = std::strstr(e.what(), "hip") != nullptr;
+        return hip ? MAA_ERR_HIP : MAA_ERR_INVALID;
+    } catch (const std::exception& e) {
+        maa::set_last_error(std::string("internal: ") + e.what());
+        return MAA_ERR_INTERNAL;
+    } catch (...) {
+        maa::set_last_error("internal: unknown exception");
+        return MAA_ERR_INTERNAL;
+    }
+}
+
+maa::StateDict to_state_dict(const maa_tensor* tensors, int n) {
+    maa::StateDict sd;
+    MAA_CHECK(tensors != nullptr || n == 0, "null tensor list");
+    for (int i = 0; i < n; ++i) {
+        const maa_tensor& t = tensors[i];
+        MAA_CHECK(t.name && t.data && t.ndim >= 0 && t.ndim <= 6, "malformed maa_tensor");
+        maa::HostTensor h;
+        h.data = t.data;
+        for (int d = 0; d < t.ndim; ++d) h.shape.push_back(t.shape[d]);
+        sd[t.name] = h;
+    }
+    return sd;
+}
+
+void bind(maa_ctx* ctx) {
+    MAA_CHECK(ctx != nullptr, "null context");
+    MAA_HIP(hipSetDevice(ctx->c.device));
+}
+
+// single-tensor state dict helpers for the operator entry points
+struct OneShot {
+    maa::StateDict sd;
+    void add(const std::string& name, const float* data, std::vector<long long> shape) {
+        maa::HostTensor h;
+        h.data = data;
+        h.shape = std::move(shape);
+        sd[name] = h;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* maa_last_error(void) { return maa::last_error_cstr(); }
+const char* maa_version(void) { return "libaudiogpt_mi355x 0.1.0 gfx950"; }
+
+int maa_ctx_create(int device_id, void* hip_stream, maa_ctx** out) {
+    return guarded([&] {
+        MAA_CHECK(out != nullptr, "null out");
+        int n = 0;
+        MAA_HIP(hipGetDeviceCount(&n));
+        MAA_CHECK(device_id >= 0 && device_id < n, "no such HIP device");
+        MAA_HIP(hipSetDevice(device_id));
+        auto* c = new maa_ctx;
+        c->c.device = device_id;
+        c->c.stream = static_cast<hipStream_t>(hip_stream);
+        *out = c;
+    });
+}
+int maa_ctx_destroy(maa_ctx* ctx) {
+    return guarded([&] {
+        if (!ctx) return;
+        (void)hipSetDevice(ctx->c.device);
+        (void)hipStreamSynchronize(ctx->c.stream);
+        delete ctx;
+    });
+}
+int maa_ctx_synchronize(maa_ctx* ctx) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_HIP(hipStreamSynchronize(ctx->c.stream));
+    });
+}
+int maa_ctx_set_stream(maa_ctx* ctx, void* hip_stream) {
+    return guarded([&] {
+        bind(ctx);
+        ctx->c.stream = static_cast<hipStream_t>(hip_stream);
+    });
+}
+int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out) {
+    return guarded([&] {
+        MAA_CHECK(ctx && out, "null argument");
+        *out = ctx->c.ws.capacity();
+    });
+}
+
+// ------------------------------------------------------------------------------------------ UNet
+int maa_unet_create(maa_ctx* ctx, const maa_unet_config* cfg, const maa_tensor* tensors, int n_tensors,
+                    maa_unet** out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(cfg && out, "null argument");
+        MAA_CHECK(cfg->n_channel_mult > 0 && cfg->n_channel_mult <= 8 && cfg->model_channels % 32 == 0,
+                  "unsupported UNet config");
+        auto sd = to_state_dict(tensors, n_tensors);
+        auto* u = new maa_unet;
+        u->m.reset(new maa::UNet(*cfg, sd));
+        *out = u;
+    });
+}
+int maa_unet_destroy(maa_unet* u) {
+    return guarded([&] { delete u; });
+}
+int maa_unet_set_context(maa_ctx* ctx, maa_unet* u, const float* d_context, int B, int L) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(u && d_context && B > 0 && L > 0, "bad set_context arguments");
+        u->m->set_context(ctx->c, d_context, B, L);
+    });
+}
+int maa_unet_forward(maa_ctx* ctx, maa_unet* u, const float* d_x, const float* d_t, int B, int H, int W,
+                     float* d_out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(u && d_x && d_t && d_out && B > 0 && H > 0 && W > 0, "bad forward arguments");
+        u->m->forward(ctx->c, d_x, d_t, u->m->context_ptr, B, H, W, d_out);
+    });
+}
+
+int maa_ddim_update(maa_ctx* ctx, const float* d_x, const float* d_eps_uncond, const float* d_eps_cond, float scale,
+                    const float* d_coef, int64_t n, float* d_x_prev, float* d_pred_x0) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d_x && d_eps_uncond && d_coef && d_x_prev && n > 0, "bad ddim_update arguments");
+        maa::launch_ddim_update(ctx->c, d_x, d_eps_uncond, d_eps_cond, scale, d_coef, n, d_x_prev, d_pred_x0);
+    });
+}
+int maa_ddim_sample(maa_ctx* ctx, maa_unet* u, const maa_ddim_args* args, float* d_x) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(u && args && d_x && args->h_timesteps && args->h_alphas && args->h_alphas_prev, "bad ddim_sample arguments");
+        maa::ddim_sample(ctx->c, *u->m, *args, d_x);
+    });
+}
+
+// ------------------------------------------------------------------------------------------ VAE
+int maa_vae_create(maa_ctx* ctx, const maa_vae_config* cfg, const maa_tensor* tensors, int n_tensors, maa_vae** out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(cfg && out && cfg->n_ch_mult > 0 && cfg->n_ch_mult <= 8, "bad VAE config");
+        auto sd = to_state_dict(tensors, n_tensors);
+        auto* v = new maa_vae;
+        v->m.reset(new maa::VAE(*cfg, sd));
+        *out = v;
+    });
+}
+int maa_vae_destroy(maa_vae* v) {
+    return guarded([&] { delete v; });
+}
+int maa_vae_decode(maa_ctx* ctx, maa_vae* v, const float* d_z, int B, int h, int w, float inv_scale, float* d_mel) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(v && d_z && d_mel && B > 0 && h > 0 && w > 0, "bad vae_decode arguments");
+        v->m->decode(ctx->c, d_z, B, h, w, inv_scale, d_mel);
+    });
+}
+int maa_vae_encode_moments(maa_ctx* ctx, maa_vae* v, const float* d_mel, int B, int H, int W, float* d_moments) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(v && d_mel && d_moments && B > 0 && H > 0 && W > 0, "bad vae_encode arguments");
+        v->m->encode_moments(ctx->c, d_mel, B, H, W, d_moments);
+    });
+}
+
+// ------------------------------------------------------------------------------------------ vocoder
+int maa_vocoder_create(maa_ctx* ctx, const maa_vocoder_config* cfg, const maa_tensor* tensors, int n_tensors,
+                       maa_vocoder** out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(cfg && out && cfg->n_upsamples > 0 && cfg->n_upsamples <= 8 && cfg->n_kernels > 0 &&
+                      cfg->n_kernels <= 8 && cfg->n_dilations > 0 && cfg->n_dilations <= 8,
+                  "bad vocoder config");
+        auto sd = to_state_dict(tensors, n_tensors);
+        auto* v = new maa_vocoder;
+        v->m.reset(new maa::Vocoder(*cfg, sd));
+        *out = v;
+    });
+}
+int maa_vocoder_destroy(maa_vocoder* v) {
+    return guarded([&] { delete v; });
+}
+int maa_vocoder_forward(maa_ctx* ctx, maa_vocoder* v, const float* d_mel, int B, int T, float* d_wav) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(v && d_mel && d_wav && B > 0 && T > 0, "bad vocoder_forward arguments");
+        v->m->forward(ctx->c, d_mel, B, T, d_wav);
+    });
+}
+
+// ------------------------------------------------------------------------------------------ operators
+int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w, const float* h_bias, int N,
+                  int geglu, float* d_y) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d_a && h_w && d_y && M > 0 && K > 0 && N > 0, "bad op_linear arguments");
+        OneShot s;
+        s.add("w", h_w, {N, K});
+        if (h_bias) s.add("b", h_bias, {N});
+        maa::WeightStore ws;
+        maa::Ctx& c = ctx->c;
+        if (geglu) {
+            MAA_CHECK(h_bias, "geglu needs a bias");
+            maa::PackedW pw = ws.pack_geglu(s.sd, "w", "b");
+            maa::linear_into(c, d_a, K, M, K, pw, nullptr, 0, d_y, N / 2, 1);
+        } else {
+            maa::PackedW pw = ws.pack_conv(s.sd, "w", h_bias ? "b" : "", 1, 1);
+            maa::linear_into(c, d_a, K, M, K, pw, nullptr, 0, d_y, N);
+        }
+        MAA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
+int maa_op_conv(maa_ctx* ctx, const float* d_x, int B, int Cin, int H, int W, const float* h_w, const float* h_bias,
+                int Cout, int KH, int KW, int stride, int pad, int dil, int upsample2, float leaky_slope, float* d_y,
+                int Ho, int Wo) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d_x && h_w && d_y, "bad op_conv arguments");
+        OneShot s;
+        s.add("w", h_w, {Cout, Cin, KH, KW});
+        if (h_bias) s.add("b", h_bias, {Cout});
+        maa::WeightStore ws;
+        maa::Ctx& c = ctx->c;
+        maa::PackedW pw = ws.pack_conv(s.sd, "w", h_bias ? "b" : "", KH, KW);
+        maa::run_sized(c, [&] {
+            maa::T4 x = maa::alloc_t(c, B, H, W, Cin);
+            maa::launch_nchw_to_nhwc(c, d_x, B, Cin, H * W, x.p);
+            maa::T4 y = maa::alloc_t(c, B, Ho, Wo, Cout);
+            maa::ConvOpt o;
+            o.KH = KH;
+            o.KW = KW;
+            o.stride = stride;
+            o.pad = pad;
+            o.dil = dil;
+            o.up = upsample2;
+            if (leaky_slope != 0.f) {
+                o.a_act = 1;
+                o.a_slope = leaky_slope;
+            }
+            maa::conv_into(c, x, nullptr, pw, o, y);
+            maa::launch_nhwc_to_nchw(c, y.p, B, Cout, Ho * Wo, d_y, Cout);
+        });
+        MAA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
+int maa_op_groupnorm(maa_ctx* ctx, const float* d_x, int B, int C, int HW, const float* h_gamma, const float* h_beta,
+                     float eps, int silu, float* d_y) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d_x && h_gamma && h_beta && d_y, "bad op_groupnorm arguments");
+        maa::WeightStore ws;
+        maa::Ctx& c = ctx->c;
+        float* g = ws.upload(std::vector<float>(h_gamma, h_gamma + C));
+        float* b = ws.upload(std::vector<float>(h_beta, h_beta + C));
+        maa::run_sized(c, [&] {
+            maa::T4 x = maa::alloc_t(c, B, 1, HW, C), y = maa::alloc_t(c, B, 1, HW, C);
+            maa::launch_nchw_to_nhwc(c, d_x, B, C, HW, x.p);
+            maa::launch_groupnorm(c, x.p, C, C, nullptr, 0, 0, B, HW, 32, g, b, eps, silu, y.p);
+            maa::launch_nhwc_to_nchw(c, y.p, B, C, HW, d_y, C);
+        });
+        MAA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
+int maa_op_layernorm(maa_ctx* ctx, const float* d_x, int rows, int C, const float* h_gamma, const float* h_beta,
+                     float eps, float* d_y) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d_x && h_gamma && h_beta && d_y, "bad op_layernorm arguments");
+        maa::WeightStore ws;
+        maa::Ctx& c = ctx->c;
+        float* g = ws.upload(std::vector<float>(h_gamma, h_gamma + C));
+        float* b = ws.upload(std::vector<float>(h_beta, h_beta + C));
+        maa::launch_layernorm(c, d_x, rows, C, g, b, eps, d_y);
+        MAA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
+int maa_op_attention(maa_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, int B, int heads, int dh,
+                     int Nq, int Nk, float alpha, float* d_y) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d_q && d_k && d_v && d_y, "bad op_attention arguments");
+        maa::Ctx& c = ctx->c;
+        const int C = heads * dh;
+        maa::run_sized(c, [&] {
+            maa::attention_into(c, d_q, C, dh, d_k, C, dh, d_v, C, dh, B, heads, dh, Nq, Nk, alpha, d_y, C);
+        });
+        MAA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
+int maa_op_conv_transpose1d(maa_ctx* ctx, const float* d_x, int B, int Cin, int L, const float* h_w,
+                            const float* h_bias, int Cout, int k, int stride, float leaky_slope, float* d_y) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d_x && h_w && h_bias && d_y, "bad op_conv_transpose1d arguments");
+        OneShot s;
+        s.add("w", h_w, {Cin, Cout, k});
+        s.add("b", h_bias, {Cout});
+        maa::WeightStore ws;
+        maa::Ctx& c = ctx->c;
+        const int pad = (k - stride) / 2, U = k / stride;
+        maa::run_sized(c, [&] {
+            maa::T4 x = maa::alloc_t(c, B, 1, L, Cin), y = maa::alloc_t(c, B, 1, L * stride, Cout);
+            maa::launch_nchw_to_nhwc(c, d_x, B, Cin, L, x.p);
+            for (int carry = 0; carry < 2; ++carry) {
+                bool any = false;
+                for (int r = 0; r < stride; ++r) any = any || ((r + pad) / stride == carry);
+                if (!any) continue;
+                int r_start = 0, r_count = 0;
+                maa::PackedW pw;
+                if (!c.ws.dry) pw = ws.pack_convtr_phase(s.sd, "w", "b", stride, pad, carry, &r_start, &r_count);
+                maa::IGemm p;
+                p.a1 = x.p;
+                p.lda1 = Cin;
+                p.C1 = Cin;
+                p.Win = L;
+                p.Wout = L;
+                p.KW = U;
+                p.pw = U - 1 - carry;
+                if (leaky_slope != 0.f) {
+                    p.a_act = 1;
+                    p.a_slope = leaky_slope;
+                }
+                p.b = pw.w;
+                p.ldb = pw.Npad;
+                p.M = B * L;
+                p.K = U * Cin;
+                p.N = r_count * Cout;
+                p.bias = pw.bias;
+                p.c = y.p + (long long)r_start * Cout;
+                p.ldc = stride * Cout;
+                if (!c.ws.dry) maa::launch_igemm(c, p);
+            }
+            maa::launch_nhwc_to_nchw(c, y.p, B, Cout, L * stride, d_y, Cout);
+        });
+        MAA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
+int maa_op_snake_aa(maa_ctx* ctx, const float* d_x, int B, int C, int L, const float* h_alpha, const float* h_beta,
+                    int logscale, float* d_y) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d_x && h_alpha && h_beta && d_y, "bad op_snake_aa arguments");
+        maa::WeightStore ws;
+        maa::Ctx& c = ctx->c;
+        std::vector<float> ha(C), hib(C);
+        for (int i = 0; i < C; ++i) {
+            float a = h_alpha[i], b = h_beta[i];
+            if (logscale) {
+                a = std::exp(a);
+                b = std::exp(b);
+            }
+            ha[i] = a;
+            hib[i] = 1.0f / (b + 1e-9f);
+        }
+        float* da = ws.upload(ha);
+        float* dib = ws.upload(hib);
+        maa::run_sized(c, [&] {
+            maa::T4 x = maa::alloc_t(c, B, 1, L, C), y = maa::alloc_t(c, B, 1, L, C);
+            maa::launch_nchw_to_nhwc(c, d_x, B, C, L, x.p);
+            maa::launch_snake_aa(c, x.p, B, L, C, dib, da, y.p);
+            maa::launch_nhwc_to_nchw(c, y.p, B, C, L, d_y, C);
+        });
+        MAA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+#include "blocks.h"
+
+namespace maa {
+
+void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const ConvOpt& o, T4& out) {
+    IGemm p;
+    p.a1 = x1.p;
+    p.lda1 = x1.C;
+    p.C1 = x1.C;
+    if (x2) {
+        MAA_CHECK(x2->B == x1.B && x2->H == x1.H && x2->W == x1.W, "concat sources differ in shape");
+        p.a2 = x2->p;
+        p.lda2 = x2->C;
+        p.C2 = x2->C;
+    }
+    p.Hin = x1.H;
+    p.Win = x1.W;
+    p.Hout = out.H;
+    p.Wout = out.W;
+    p.KH = o.KH;
+    p.KW = o.KW;
+    p.sh = p.sw = o.stride;
+    p.dh = p.dw = o.dil;
+    p.pw = o.pad;
+    p.ph = o.pad_h >= 0 ? o.pad_h : (o.KH > 1 ? o.pad : 0);
+    p.up = o.up;
+    p.a_act = o.a_act;
+    p.a_slope = o.a_slope;
+    p.b = w.w;
+    p.ldb = w.Npad;
+    p.M = out.B * out.H * out.W;
+    p.K = o.KH * o.KW * (p.C1 + p.C2);
+    MAA_CHECK(p.K == w.K, "conv weight K mismatch");
+    p.N = o.geglu ? w.N : out.C;
+    MAA_CHECK(p.N <= w.N, "conv weight N mismatch");
+    p.bias = w.bias;
+    p.rowadd = o.rowadd;
+    p.ld_rowadd = o.ld_rowadd;
+    p.res = o.res;
+    p.ldr = out.C;
+    p.act = o.act;
+    p.out_scale = o.out_scale;
+    p.accumulate = o.accumulate;
+    p.geglu = o.geglu;
+    p.c = out.p;
+    p.ldc = out.C;
+    launch_igemm(ctx, p);
+}
+
+void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const PackedW& w, const float* res,
+                 int ldr, float* out, int ldc, int geglu, int a_act) {
+    IGemm p;
+    p.a1 = a;
+    p.lda1 = lda;
+    p.C1 = K;
+    p.Hout = 1;
+    p.Wout = 1;
+    p.M = (int)rows;
+    p.K = K;
+    MAA_CHECK(K == w.K, "linear weight K mismatch");
+    p.N = w.N;
+    p.b = w.w;
+    p.ldb = w.Npad;
+    p.bias = w.bias;
+    p.res = res;
+    p.ldr = ldr;
+    p.geglu = geglu;
+    p.a_act = a_act;
+    p.c = out;
+    p.ldc = ldc;
+    launch_igemm(ctx, p);
+}
+
+void attention_into(Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk, const float* v,
+                    int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha, float* out, int ldo) {
+    const size_t mk = ctx.ws.mark();
+    const int ldS = (Nk + 3) / 4 * 4;
+    float* S = ctx.ws.alloc_f((size_t)B * heads * Nq * ldS);
+    IGemm p;
+    p.a1 = q;
+    p.lda1 = ldq;
+    p.C1 = dh;
+    p.M = Nq;
+    p.K = dh;
+    p.N = Nk;
+    p.b = k;
+    p.ldb = ldk;
+    p.b_nk = 1;
+    p.Z = B * heads;
+    p.zin = heads;
+    p.a_so = (long long)Nq * ldq;
+    p.a_si = hsq;
+    p.b_so = (long long)Nk * ldk;
+    p.b_si = hsk;
+    p.c_so = (long long)heads * Nq * ldS;
+    p.c_si = (long long)Nq * ldS;
+    p.alpha = alpha;
+    p.c = S;
+    p.ldc = ldS;
+    launch_igemm(ctx, p);
+    launch_softmax(ctx, S, (long long)B * heads * Nq, Nk, ldS);
+    IGemm r;
+    r.a1 = S;
+    r.lda1 = ldS;
+    r.C1 = Nk;
+    r.M = Nq;
+    r.K = Nk;
+    r.N = dh;
+    r.b = v;
+    r.ldb = ldv;
+    r.Z = B * heads;
+    r.zin = heads;
+    r.a_so = (long long)heads * Nq * ldS;
+    r.a_si = (long long)Nq * ldS;
+    r.b_so = (long long)Nk * ldv;
+    r.b_si = hsv;
+    r.c_so = (long long)Nq * ldo;
+    r.c_si = dh;
+    r.c = out;
+    r.ldc = ldo;
+    launch_igemm(ctx, r);
+    ctx.ws.release(mk);
+}
+
+}  // namespace maa

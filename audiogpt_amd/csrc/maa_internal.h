@@ -1,0 +1,175 @@
+// Internal declarations of libaudiogpt_mi355x: context, workspace arena, kernel launchers.
+// gfx950 only.  Activations are channels-last fp32: images [B, H, W, C], sequences [B, L, C].
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace maa {
+
+// ------------------------------------------------------------------------------------------ errors
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+void set_last_error(const std::string& s);
+
+#define MAA_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            throw ::maa::Error(std::string(#expr) + ": " + hipGetErrorString(_e));                 \
+    } while (0)
+#define MAA_CHECK(cond, msg)                                                                       \
+    do {                                                                                           \
+        if (!(cond)) throw ::maa::Error(std::string("check failed: ") + #cond + " -- " + (msg));   \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------ arena
+// Bump allocator over one hipMalloc'd slab.  Nothing is allocated while a forward runs (hipGraph
+// capture safe): the slab is grown only between forwards (`reserve`).
+class Arena {
+public:
+    ~Arena();
+    void reserve(size_t bytes);                 // (re)allocate the slab if smaller; not during capture
+    void reset() { off_ = 0; run_high_ = 0; }
+    size_t mark() const { return off_; }
+    void release(size_t m) { off_ = m; }
+    float* alloc_f(size_t n_floats);
+    size_t capacity() const { return cap_; }
+    size_t high_water() const { return high_; }
+    size_t mark_high() const { return run_high_; }   // high-water since the last reset()
+    // when true, alloc only counts (dry run to size the slab)
+    bool dry = false;
+
+private:
+    char* base_ = nullptr;
+    size_t cap_ = 0, off_ = 0, high_ = 0, run_high_ = 0;
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Arena ws;
+    int dtype = 0;   // 0 = fp32 (exact-f32 MFMA); 1 = bf16 MFMA operands, fp32 accumulate/storage
+};
+
+// ------------------------------------------------------------------------------------------ igemm
+// Out[m, n] = epilogue( alpha * sum_k A[m, k] * B[k, n] ),  m = (b, oy, ox) output position,
+// k = (ky, kx, ci) with ci running over channels of src1 then src2 (virtual concat).
+struct IGemm {
+    // A operand: gathered from one or two channels-last sources
+    const float* a1 = nullptr;
+    const float* a2 = nullptr;
+    int lda1 = 0, lda2 = 0;          // elements between consecutive spatial positions
+    int C1 = 0, C2 = 0;              // channels taken from src1 / src2
+    int Hin = 1, Win = 1, Hout = 1, Wout = 1;
+    int KH = 1, KW = 1, sh = 1, sw = 1, ph = 0, pw = 0, dh = 1, dw = 1;
+    int up = 0;                      // 1: source is read through a virtual nearest-2x upsample
+    int a_act = 0;                   // 0 none, 1 leaky-relu(a_slope), 2 silu   (applied while staging A)
+    float a_slope = 0.f;
+    // B operand
+    const float* b = nullptr;
+    int ldb = 0;
+    int b_nk = 0;                    // 0: B stored [K][N] (packed weights, V);  1: stored [N][K] (K^T)
+    // dims
+    int M = 0, N = 0, K = 0;
+    // batching over blockIdx.z: z -> (zo, zi) = (z / zin, z % zin)
+    int Z = 1, zin = 1;
+    long long a_so = 0, a_si = 0, b_so = 0, b_si = 0, c_so = 0, c_si = 0;
+    // epilogue
+    float alpha = 1.f;
+    const float* bias = nullptr;     // [N]
+    const float* rowadd = nullptr;   // [B][ld_rowadd]  (time-embedding add)
+    int ld_rowadd = 0;               // row index = m / (Hout*Wout)
+    const float* res = nullptr;      // residual, same indexing as c
+    int ldr = 0;
+    int geglu = 0;                   // value/gate column interleave (see pack.cpp), writes N/2 columns
+    int act = 0;                     // 0 none, 1 tanh
+    float out_scale = 1.f;           // applied after bias/residual/act
+    int accumulate = 0;              // c += value instead of c = value
+    float* c = nullptr;
+    int ldc = 0;
+};
+void launch_igemm(const Ctx& ctx, const IGemm& p);
+
+// ------------------------------------------------------------------------------------------ norms etc.
+// GroupNorm(32 groups) over a channels-last tensor given as a virtual concat of two sources; writes
+// a dense [B, HW, C1+C2] tensor.  silu: fuse x*sigmoid(x).
+void launch_groupnorm(const Ctx& ctx, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2,
+                      int B, int HW, int groups, const float* gamma, const float* beta, float eps, int silu,
+                      float* out);
+void launch_layernorm(const Ctx& ctx, const float* x, int rows, int C, const float* gamma, const float* beta,
+                      float eps, float* out);
+// in-place row softmax over `cols` columns of a [rows, ld] matrix; columns [cols, ld) are zeroed
+void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld);
+
+// ------------------------------------------------------------------------------------------ elementwise
+void launch_timestep_embedding(const Ctx& ctx, const float* t, int B, int dim, float* out);   // [cos | sin]
+void launch_silu(const Ctx& ctx, const float* x, long long n, float* out);
+void launch_add(const Ctx& ctx, const float* a, const float* b, long long n, float* out);
+void launch_nchw_to_nhwc(const Ctx& ctx, const float* x, int B, int C, int HW, float* out);
+void launch_nhwc_to_nchw(const Ctx& ctx, const float* x, int B, int C, int HW, float* out, int ld_in);
+void launch_avgpool2(const Ctx& ctx, const float* x, int B, int H, int W, int C, float* out);
+void launch_upsample2(const Ctx& ctx, const float* x, int B, int H, int W, int C, float* out);
+void launch_scale(const Ctx& ctx, const float* x, long long n, float s, float* out);
+// eps = eu + scale*(ec - eu); x0 = (x - somat*eps)/sqrt(a_t); x' = sqrt(a_prev)*x0 + sqrt(1-a_prev-sig^2)*eps
+// coef = device pointer to {a_t, a_prev, sigma, sqrt_one_minus_at}; eps_c may be null (no CFG)
+void launch_ddim_update(const Ctx& ctx, const float* x, const float* eps_u, const float* eps_c, float scale,
+                        const float* coef, long long n, float* x_prev, float* pred_x0);
+// BigVGAN Activation1d on [B, L, C]: up2 FIR -> snake -> down2 FIR (replicate padding)
+void launch_snake_aa(const Ctx& ctx, const float* x, int B, int L, int C, const float* inv_beta, const float* alpha,
+                     float* out);
+void launch_leaky(const Ctx& ctx, const float* x, long long n, float slope, float* out);
+void launch_clamp_affine(const Ctx& ctx, const float* x, long long n, float mul, float add, float lo, float hi,
+                         float* out);
+
+// ------------------------------------------------------------------------------------------ weights
+struct HostTensor {
+    const float* data = nullptr;
+    std::vector<long long> shape;
+    long long numel() const {
+        long long n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+using StateDict = std::map<std::string, HostTensor>;
+
+// device-resident packed weight for the igemm B operand: [K][Npad] fp32
+struct PackedW {
+    float* w = nullptr;     // [K][Npad]
+    float* bias = nullptr;  // [Npad] or null
+    int K = 0, N = 0, Npad = 0;
+};
+
+class WeightStore {
+public:
+    ~WeightStore();
+    float* upload(const std::vector<float>& host);
+    // conv / linear weight [Cout][Cin][KH][KW] (linear: KH=KW=1) -> [ (ky,kx,ci) ][Cout pad 32]
+    PackedW pack_conv(const StateDict& sd, const std::string& wname, const std::string& bname, int KH, int KW);
+    // several linears sharing the input, concatenated on the output axis
+    PackedW pack_concat(const StateDict& sd, const std::vector<std::string>& wnames,
+                        const std::vector<std::string>& bnames);
+    // GEGLU projection: value/gate columns interleaved in groups of 32 (see igemm epilogue)
+    PackedW pack_geglu(const StateDict& sd, const std::string& wname, const std::string& bname);
+    // ConvTranspose1d weight [Cin][Cout][k], stride s, padding p: polyphase group `carry` (0/1)
+    PackedW pack_convtr_phase(const StateDict& sd, const std::string& wname, const std::string& bname, int stride,
+                              int pad, int carry, int* r_start, int* r_count);
+    float* vec(const StateDict& sd, const std::string& name);
+    size_t bytes() const { return bytes_; }
+
+private:
+    std::vector<void*> bufs_;
+    size_t bytes_ = 0;
+};
+
+const HostTensor& get(const StateDict& sd, const std::string& name);
+bool has(const StateDict& sd, const std::string& name);
+
+}  // namespace maa

@@ -1,0 +1,261 @@
+// Small elementwise / layout kernels of the hot path (all HBM-bound, grid-stride, coalesced).
+//   timestep embedding [cos | sin]      ldm/modules/diffusionmodules/util.py:151-171
+//   CFG combine + DDIM x_{t-1} update   ldm/models/diffusion/ddim.py:199, 210-225
+//   avg-pool 2x2 / nearest 2x           openaimodel.py:209-216 (resblock_updown), :116-118
+//   BigVGAN Activation1d                vocoder/bigvgan/alias_free_torch/{act.py:23-27,resample.py:25-33,46-49,
+//                                       filter.py:28-57,86-94}, activations.py:107-119
+#include "maa_internal.h"
+
+#include <cmath>
+
+namespace maa {
+namespace {
+
+inline dim3 grid_for(long long n, int per_block = 256) {
+    long long b = (n + per_block - 1) / per_block;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return dim3((unsigned)b);
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int B, int dim, float* __restrict__ out) {
+    const int half = dim / 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * half; i += gridDim.x * blockDim.x) {
+        const int b = i / half, j = i - b * half;
+        // freqs = exp(-ln(10000) * j / half) in fp32, as torch.exp over an fp32 arange
+        const float f = expf(-9.210340371976184f * (float)j / (float)half);
+        const float a = t[b] * f;
+        out[(long long)b * dim + j] = cosf(a);
+        out[(long long)b * dim + half + j] = sinf(a);
+    }
+}
+
+__global__ void silu_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        out[i] = v / (1.f + expf(-v));
+    }
+}
+
+__global__ void leaky_kernel(const float* __restrict__ x, long long n, float slope, float* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        out[i] = v > 0.f ? v : v * slope;
+    }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                           float* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+
+__global__ void scale_kernel(const float* __restrict__ x, long long n, float s, float* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = x[i] * s;
+}
+
+__global__ void clamp_affine_kernel(const float* __restrict__ x, long long n, float mul, float add, float lo,
+                                    float hi, float* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = fminf(fmaxf(x[i] * mul + add, lo), hi);
+}
+
+// x [B, C, HW] -> out [B, HW, C]
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int B, int C, int HW, float* __restrict__ out) {
+    const long long n = (long long)B * C * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long r = i / C;
+        const int p = (int)(r % HW);
+        const int b = (int)(r / HW);
+        out[i] = x[((long long)b * C + c) * HW + p];
+    }
+}
+
+// x [B, HW, ld_in] (first C channels) -> out [B, C, HW]
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int B, int C, int HW, int ld_in,
+                                    float* __restrict__ out) {
+    const long long n = (long long)B * C * HW;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const long long r = i / HW;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        out[i] = x[((long long)b * HW + p) * ld_in + c];
+    }
+}
+
+__global__ void avgpool2_kernel(const float* __restrict__ x, int B, int H, int W, int C, float* __restrict__ out) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long n = (long long)B * Ho * Wo * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float* s = x + (((long long)b * H + 2 * oy) * W + 2 * ox) * C + c;
+        // same summation order as ATen's avg_pool2d (row-major over the window), then divide
+        out[i] = (s[0] + s[C] + s[(long long)W * C] + s[(long long)W * C + C]) / 4.f;
+    }
+}
+
+__global__ void upsample2_kernel(const float* __restrict__ x, int B, int H, int W, int C, float* __restrict__ out) {
+    const int Ho = H * 2, Wo = W * 2;
+    const long long n = (long long)B * Ho * Wo * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long r = i / C;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        out[i] = x[(((long long)b * H + (oy >> 1)) * W + (ox >> 1)) * C + c];
+    }
+}
+
+__global__ void ddim_update_kernel(const float* __restrict__ x, const float* __restrict__ eu,
+                                   const float* __restrict__ ec, float scale, const float* __restrict__ coef,
+                                   long long n, float* __restrict__ x_prev, float* __restrict__ pred_x0) {
+    const float a_t = coef[0], a_prev = coef[1], sigma = coef[2], somat = coef[3];
+    const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev), dir = sqrtf(1.f - a_prev - sigma * sigma);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float e = eu[i];
+        if (ec) e = e + scale * (ec[i] - e);
+        const float x0 = (x[i] - somat * e) / sqrt_at;
+        x_prev[i] = sqrt_ap * x0 + dir * e;
+        if (pred_x0) pred_x0[i] = x0;
+    }
+}
+
+// 12-tap Kaiser-sinc low-pass (cutoff 0.25, half-width 0.3): alias_free_torch/filter.py:28-57 restated on the host
+__constant__ float c_fir12[12];
+
+static double bessel_i0(double x) {
+    double sum = 1.0, term = 1.0;
+    const double q = x * x / 4.0;
+    for (int k = 1; k < 64; ++k) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+static void kaiser_sinc_filter12(float* out) {
+    const int ks = 12, half = 6;
+    const double cutoff = 0.25, half_width = 0.3, pi = 3.14159265358979323846;
+    const double delta_f = 4.0 * half_width;
+    const double A = 2.285 * (half - 1) * pi * delta_f + 7.95;
+    double beta = 0.0;
+    if (A > 50.0)
+        beta = 0.1102 * (A - 8.7);
+    else if (A >= 21.0)
+        beta = 0.5842 * std::pow(A - 21.0, 0.4) + 0.07886 * (A - 21.0);
+    double f[12], sum = 0.0;
+    for (int n = 0; n < ks; ++n) {
+        const double r = (2.0 * n) / (ks - 1) - 1.0;                       // kaiser_window(periodic=False)
+        const double w = bessel_i0(beta * std::sqrt(1.0 - r * r)) / bessel_i0(beta);
+        const double t = (n - half) + 0.5;                                 // even kernel: arange(-6, 6) + 0.5
+        const double xx = 2.0 * cutoff * t;
+        const double sinc = xx == 0.0 ? 1.0 : std::sin(pi * xx) / (pi * xx);
+        f[n] = 2.0 * cutoff * w * sinc;
+        sum += f[n];
+    }
+    for (int n = 0; n < ks; ++n) out[n] = (float)(f[n] / sum);
+}
+
+// out[b,l,c] = sum_j f[j] * snake( up[2l + j - 5] ),  up[u] = 2 * sum_i f[.] x_rep[...]   (replicate edges)
+//   UpSample1d : pad 5 replicate -> 2*conv_transpose(stride 2) -> crop [15:-15]       resample.py:25-33
+//   DownSample1d: pad (5,6) replicate -> conv stride 2                                 filter.py:86-94
+__global__ void snake_aa_kernel(const float* __restrict__ x, int B, int L, int C, const float* __restrict__ inv_beta,
+                                const float* __restrict__ alpha, float* __restrict__ out) {
+    const long long n = (long long)B * L * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long long r = i / C;
+        const int l = (int)(r % L);
+        const int b = (int)(r / L);
+        const float* xs = x + (long long)b * L * C + c;
+        const float al = alpha[c], ib = inv_beta[c];
+        const int U = 2 * L;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            int u = 2 * l + j - 5;                 // index into the upsampled signal, replicate-clamped
+            u = u < 0 ? 0 : (u >= U ? U - 1 : u);
+            // upsampled[u] = 2 * sum_k f[k] * xpad[(u + 15 - k) / 2] for (u + 15 - k) even, xpad = replicate pad 5
+            float up = 0.f;
+            const int par = (u + 15) & 1;
+#pragma unroll
+            for (int k2 = 0; k2 < 6; ++k2) {
+                const int k = 2 * k2 + par;
+                int src = ((u + 15 - k) >> 1) - 5;
+                src = src < 0 ? 0 : (src >= L ? L - 1 : src);
+                up += c_fir12[k] * xs[(long long)src * C];
+            }
+            up *= 2.f;
+            const float sn = sinf(up * al);
+            acc += c_fir12[j] * (up + ib * sn * sn);
+        }
+        out[i] = acc;
+    }
+}
+
+}  // namespace
+
+#define MAA_LAUNCH1(kern, n, ...)                                                            \
+    if (ctx.ws.dry) return;                                                                  \
+    hipLaunchKernelGGL(kern, grid_for(n), dim3(256), 0, ctx.stream, __VA_ARGS__);            \
+    MAA_HIP(hipGetLastError())
+
+void launch_timestep_embedding(const Ctx& ctx, const float* t, int B, int dim, float* out) {
+    MAA_LAUNCH1(timestep_embedding_kernel, (long long)B * dim / 2, t, B, dim, out);
+}
+void launch_silu(const Ctx& ctx, const float* x, long long n, float* out) { MAA_LAUNCH1(silu_kernel, n, x, n, out); }
+void launch_leaky(const Ctx& ctx, const float* x, long long n, float slope, float* out) {
+    MAA_LAUNCH1(leaky_kernel, n, x, n, slope, out);
+}
+void launch_add(const Ctx& ctx, const float* a, const float* b, long long n, float* out) {
+    MAA_LAUNCH1(add_kernel, n, a, b, n, out);
+}
+void launch_scale(const Ctx& ctx, const float* x, long long n, float s, float* out) {
+    MAA_LAUNCH1(scale_kernel, n, x, n, s, out);
+}
+void launch_clamp_affine(const Ctx& ctx, const float* x, long long n, float mul, float add, float lo, float hi,
+                         float* out) {
+    MAA_LAUNCH1(clamp_affine_kernel, n, x, n, mul, add, lo, hi, out);
+}
+void launch_nchw_to_nhwc(const Ctx& ctx, const float* x, int B, int C, int HW, float* out) {
+    MAA_LAUNCH1(nchw_to_nhwc_kernel, (long long)B * C * HW, x, B, C, HW, out);
+}
+void launch_nhwc_to_nchw(const Ctx& ctx, const float* x, int B, int C, int HW, float* out, int ld_in) {
+    MAA_LAUNCH1(nhwc_to_nchw_kernel, (long long)B * C * HW, x, B, C, HW, ld_in, out);
+}
+void launch_avgpool2(const Ctx& ctx, const float* x, int B, int H, int W, int C, float* out) {
+    MAA_LAUNCH1(avgpool2_kernel, (long long)B * (H / 2) * (W / 2) * C, x, B, H, W, C, out);
+}
+void launch_upsample2(const Ctx& ctx, const float* x, int B, int H, int W, int C, float* out) {
+    MAA_LAUNCH1(upsample2_kernel, (long long)B * H * W * C * 4, x, B, H, W, C, out);
+}
+void launch_ddim_update(const Ctx& ctx, const float* x, const float* eps_u, const float* eps_c, float scale,
+                        const float* coef, long long n, float* x_prev, float* pred_x0) {
+    MAA_LAUNCH1(ddim_update_kernel, n, x, eps_u, eps_c, scale, coef, n, x_prev, pred_x0);
+}
+
+static bool g_fir_uploaded[16] = {false};
+void launch_snake_aa(const Ctx& ctx, const float* x, int B, int L, int C, const float* inv_beta, const float* alpha,
+                     float* out) {
+    if (ctx.ws.dry) return;
+    if (!g_fir_uploaded[ctx.device & 15]) {
+        float f[12];
+        kaiser_sinc_filter12(f);
+        MAA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fir12), f, sizeof(f)));
+        g_fir_uploaded[ctx.device & 15] = true;
+    }
+    MAA_LAUNCH1(snake_aa_kernel, (long long)B * L * C, x, B, L, C, inv_beta, alpha, out);
+}
+
+}  // namespace maa

@@ -1,0 +1,52 @@
+// Model executors behind the C ABI handles.
+#pragma once
+#include "../../include/maa.h"
+#include "blocks.h"
+
+namespace maa {
+
+class UNet {
+public:
+    UNet(const maa_unet_config& cfg, const StateDict& sd);
+    ~UNet();
+    void set_context(Ctx& ctx, const float* d_context, int B, int L);
+    void forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
+                 float* out_nchw);
+    const maa_unet_config& config() const;
+    size_t weight_bytes() const;
+    // context pointer remembered by set_context (needed by the I2A time-embedding add)
+    const float* context_ptr = nullptr;
+
+private:
+    struct Impl;
+    Impl* impl_;
+};
+
+class VAE {
+public:
+    VAE(const maa_vae_config& cfg, const StateDict& sd);
+    ~VAE();
+    void decode(Ctx& ctx, const float* z_nchw, int B, int h, int w, float inv_scale, float* mel_nchw);
+    void encode_moments(Ctx& ctx, const float* mel_nchw, int B, int H, int W, float* moments_nchw);
+    const maa_vae_config& config() const;
+
+private:
+    struct Impl;
+    Impl* impl_;
+};
+
+class Vocoder {
+public:
+    Vocoder(const maa_vocoder_config& cfg, const StateDict& sd);
+    ~Vocoder();
+    void forward(Ctx& ctx, const float* mel, int B, int T, float* wav);
+    int hop() const;
+
+private:
+    struct Impl;
+    Impl* impl_;
+};
+
+void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x);
+
+}  // namespace maa

@@ -1,0 +1,193 @@
+// Runtime support: workspace arena, weight store and host-side weight repacking.
+//
+// Packed layout for every igemm B operand: row index k = (ky*KW + kx)*Cin + ci, column = output channel,
+// zero-padded to a multiple of 32 columns.  Reference weight layouts being repacked:
+//   Conv2d [Cout][Cin][KH][KW], Conv1d [Cout][Cin][k], Linear [Cout][Cin]   (torch.nn defaults)
+//   ConvTranspose1d [Cin][Cout][k]  (NeuralSeq/modules/hifigan/hifigan.py:121-125)
+#include "maa_internal.h"
+
+#include <cstring>
+
+namespace maa {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+const char* last_error_cstr() { return g_last_error.c_str(); }
+
+// ------------------------------------------------------------------------------------------ Arena
+Arena::~Arena() {
+    if (base_) (void)hipFree(base_);
+}
+void Arena::reserve(size_t bytes) {
+    if (bytes <= cap_) return;
+    if (base_) MAA_HIP(hipFree(base_));
+    base_ = nullptr;
+    cap_ = 0;
+    MAA_HIP(hipMalloc(reinterpret_cast<void**>(&base_), bytes));
+    cap_ = bytes;
+}
+float* Arena::alloc_f(size_t n_floats) {
+    const size_t bytes = (n_floats * sizeof(float) + 255) / 256 * 256;
+    const size_t at = off_;
+    off_ += bytes;
+    if (off_ > high_) high_ = off_;
+    if (off_ > run_high_) run_high_ = off_;
+    if (dry) return reinterpret_cast<float*>(static_cast<uintptr_t>(0x1000) + at);   // never dereferenced
+    if (off_ > cap_) throw Error("workspace arena exhausted (" + std::to_string(off_) + " > " + std::to_string(cap_) + ")");
+    return reinterpret_cast<float*>(base_ + at);
+}
+
+// ------------------------------------------------------------------------------------------ StateDict helpers
+const HostTensor& get(const StateDict& sd, const std::string& name) {
+    auto it = sd.find(name);
+    if (it == sd.end()) throw Error("missing weight tensor: " + name);
+    return it->second;
+}
+bool has(const StateDict& sd, const std::string& name) { return sd.find(name) != sd.end(); }
+
+// ------------------------------------------------------------------------------------------ WeightStore
+WeightStore::~WeightStore() {
+    for (void* p : bufs_) (void)hipFree(p);
+}
+float* WeightStore::upload(const std::vector<float>& host) {
+    void* d = nullptr;
+    const size_t bytes = host.size() * sizeof(float);
+    MAA_HIP(hipMalloc(&d, bytes ? bytes : 4));
+    if (bytes) MAA_HIP(hipMemcpy(d, host.data(), bytes, hipMemcpyHostToDevice));
+    bufs_.push_back(d);
+    bytes_ += bytes;
+    return static_cast<float*>(d);
+}
+float* WeightStore::vec(const StateDict& sd, const std::string& name) {
+    const HostTensor& t = get(sd, name);
+    return upload(std::vector<float>(t.data, t.data + t.numel()));
+}
+
+static int pad32(int n) { return (n + 31) / 32 * 32; }
+
+PackedW WeightStore::pack_conv(const StateDict& sd, const std::string& wname, const std::string& bname, int KH,
+                               int KW) {
+    const HostTensor& w = get(sd, wname);
+    MAA_CHECK(w.shape.size() >= 2, wname);
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1];
+    MAA_CHECK(w.numel() == (long long)Cout * Cin * KH * KW, "conv weight shape " + wname);
+    PackedW pw;
+    pw.K = KH * KW * Cin;
+    pw.N = Cout;
+    pw.Npad = pad32(Cout);
+    std::vector<float> h((size_t)pw.K * pw.Npad, 0.f);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < KH * KW; ++t)
+                h[((size_t)t * Cin + ci) * pw.Npad + co] = w.data[((size_t)co * Cin + ci) * KH * KW + t];
+    pw.w = upload(h);
+    if (!bname.empty()) {
+        const HostTensor& b = get(sd, bname);
+        std::vector<float> hb(pw.Npad, 0.f);
+        std::memcpy(hb.data(), b.data, sizeof(float) * Cout);
+        pw.bias = upload(hb);
+    }
+    return pw;
+}
+
+PackedW WeightStore::pack_concat(const StateDict& sd, const std::vector<std::string>& wnames,
+                                 const std::vector<std::string>& bnames) {
+    int N = 0, Cin = -1;
+    for (auto& n : wnames) {
+        const HostTensor& w = get(sd, n);
+        const int cin = (int)(w.numel() / w.shape[0]);
+        MAA_CHECK(Cin < 0 || Cin == cin, "pack_concat: input width mismatch " + n);
+        Cin = cin;
+        N += (int)w.shape[0];
+    }
+    PackedW pw;
+    pw.K = Cin;
+    pw.N = N;
+    pw.Npad = pad32(N);
+    std::vector<float> h((size_t)Cin * pw.Npad, 0.f), hb(pw.Npad, 0.f);
+    int col = 0;
+    for (size_t i = 0; i < wnames.size(); ++i) {
+        const HostTensor& w = get(sd, wnames[i]);
+        const int co_n = (int)w.shape[0];
+        for (int co = 0; co < co_n; ++co)
+            for (int ci = 0; ci < Cin; ++ci) h[(size_t)ci * pw.Npad + col + co] = w.data[(size_t)co * Cin + ci];
+        if (!bnames.empty() && !bnames[i].empty()) {
+            const HostTensor& b = get(sd, bnames[i]);
+            std::memcpy(hb.data() + col, b.data, sizeof(float) * co_n);
+        }
+        col += co_n;
+    }
+    pw.w = upload(h);
+    bool any_bias = false;
+    for (auto& b : bnames) any_bias = any_bias || !b.empty();
+    if (any_bias) pw.bias = upload(hb);
+    return pw;
+}
+
+PackedW WeightStore::pack_geglu(const StateDict& sd, const std::string& wname, const std::string& bname) {
+    // proj weight [2*inner][Cin]: rows [0, inner) = value, [inner, 2*inner) = gate  (attention.py:42-44)
+    // packed column (g*64 + j)      <- value column g*32 + j
+    //               (g*64 + 32 + j) <- gate  column g*32 + j
+    const HostTensor& w = get(sd, wname);
+    const HostTensor& b = get(sd, bname);
+    const int N2 = (int)w.shape[0], Cin = (int)w.shape[1], inner = N2 / 2;
+    MAA_CHECK(inner % 32 == 0, "geglu inner width must be a multiple of 32");
+    PackedW pw;
+    pw.K = Cin;
+    pw.N = inner;       // output columns
+    pw.Npad = N2;       // packed columns
+    std::vector<float> h((size_t)Cin * N2), hb(N2);
+    for (int j = 0; j < inner; ++j) {
+        const int g = j / 32, jj = j % 32;
+        const int cv = g * 64 + jj, cg = g * 64 + 32 + jj;
+        for (int ci = 0; ci < Cin; ++ci) {
+            h[(size_t)ci * N2 + cv] = w.data[(size_t)j * Cin + ci];
+            h[(size_t)ci * N2 + cg] = w.data[(size_t)(inner + j) * Cin + ci];
+        }
+        hb[cv] = b.data[j];
+        hb[cg] = b.data[inner + j];
+    }
+    pw.w = upload(h);
+    pw.bias = upload(hb);
+    return pw;
+}
+
+PackedW WeightStore::pack_convtr_phase(const StateDict& sd, const std::string& wname, const std::string& bname,
+                                       int stride, int pad, int carry, int* r_start, int* r_count) {
+    // out[s*j + r] = sum_u sum_ci x[j + c - u][ci] * w[ci][co][phi + s*u],  phi = (r+pad) % s, c = (r+pad) / s,
+    // u in [0, k/s).  All r with the same carry c share the input taps {j+c-u}; they are stacked on the
+    // output-column axis: column = (r - r_start)*Cout + co.  Tap order in K: kx = (U-1) - u  <->  x[j + c - U + 1 + kx].
+    const HostTensor& w = get(sd, wname);
+    const int Cin = (int)w.shape[0], Cout = (int)w.shape[1], k = (int)w.shape[2];
+    MAA_CHECK(k % stride == 0, "conv-transpose kernel must be a multiple of the stride");
+    const int U = k / stride;
+    std::vector<int> rs;
+    for (int r = 0; r < stride; ++r)
+        if ((r + pad) / stride == carry) rs.push_back(r);
+    MAA_CHECK(!rs.empty(), "empty polyphase group");
+    *r_start = rs.front();
+    *r_count = (int)rs.size();
+    MAA_CHECK(rs.back() - rs.front() + 1 == (int)rs.size(), "polyphase group not contiguous");
+    PackedW pw;
+    pw.K = U * Cin;
+    pw.N = (int)rs.size() * Cout;
+    pw.Npad = pad32(pw.N);
+    std::vector<float> h((size_t)pw.K * pw.Npad, 0.f), hb(pw.Npad, 0.f);
+    const HostTensor& b = get(sd, bname);
+    for (size_t ri = 0; ri < rs.size(); ++ri) {
+        const int phi = (rs[ri] + pad) % stride;
+        for (int kx = 0; kx < U; ++kx) {
+            const int u = U - 1 - kx;
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int co = 0; co < Cout; ++co)
+                    h[((size_t)kx * Cin + ci) * pw.Npad + ri * Cout + co] =
+                        w.data[((size_t)ci * Cout + co) * k + phi + stride * u];
+        }
+        for (int co = 0; co < Cout; ++co) hb[ri * Cout + co] = b.data[co];
+    }
+    pw.w = upload(h);
+    pw.bias = upload(hb);
+    return pw;
+}
+
+}  // namespace maa

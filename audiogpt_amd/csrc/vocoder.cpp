@@ -1,0 +1,292 @@
+// HiFi-GAN / BigVGAN MRF generator executor on channels-last sequences [B, L, C].
+//
+// Mirrors: NeuralSeq/modules/hifigan/hifigan.py:104-178 (HifiGanGenerator, f0=None), :30-67 ResBlock1
+//          text_to_audio/Make_An_Audio/vocoder/hifigan/modules.py:86-136 (same graph)
+//          text_to_audio/Make_An_Audio/vocoder/bigvgan/models.py:30-81,133-203 (AMPBlock1, BigVGAN)
+// What is fused instead of launched (same maths):
+//   * every leaky-ReLU is applied while the following conv stages its A tile
+//   * `xt + x` and the MRF mean (rb0+rb1+rb2)/3 are igemm epilogues (out_scale 1/3, accumulate)
+//   * ConvTranspose1d runs as two polyphase GEMMs writing interleaved output rows (runtime.cpp)
+//   * weight-norm (weight_g, weight_v) is folded at load exactly as remove_weight_norm does
+#include "models.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace maa {
+
+namespace {
+struct ConvK {
+    PackedW w;
+    int k = 1, dil = 1;
+};
+struct ResBlockW {
+    std::vector<ConvK> c1, c2;
+    // BigVGAN: per-activation snake parameters (device), 2 per (c1, c2) pair
+    std::vector<float*> alpha, inv_beta;
+};
+struct UpW {
+    PackedW ph[2];
+    int r_start[2] = {0, 0}, r_count[2] = {0, 0};
+    int n_groups = 0;
+    int stride = 1, k = 1, cin = 0, cout = 0;
+};
+
+// fold weight-norm pairs: w = g * v / ||v||_(dims != 0)
+struct Folded {
+    std::vector<std::vector<float>> storage;
+    StateDict sd;
+};
+void fold_weight_norm(const StateDict& in, Folded& out) {
+    for (auto& kv : in) {
+        const std::string& k = kv.first;
+        auto ends = [&](const char* suf) {
+            const size_t n = std::strlen(suf);
+            return k.size() >= n && k.compare(k.size() - n, n, suf) == 0;
+        };
+        if (ends(".weight_g")) {
+            const std::string base = k.substr(0, k.size() - 9);
+            const HostTensor& g = kv.second;
+            const HostTensor& v = get(in, base + ".weight_v");
+            const long long rows = v.shape[0], per = v.numel() / rows;
+            MAA_CHECK(g.numel() == rows, "weight_g shape " + k);
+            std::vector<float> w((size_t)v.numel());
+            for (long long r = 0; r < rows; ++r) {
+                // torch.norm_except_dim accumulates in fp32; do the same
+                float s = 0.f;
+                for (long long i = 0; i < per; ++i) s += v.data[r * per + i] * v.data[r * per + i];
+                const float scale = g.data[r] / std::sqrt(s);
+                for (long long i = 0; i < per; ++i) w[(size_t)(r * per + i)] = v.data[r * per + i] * scale;
+            }
+            out.storage.push_back(std::move(w));
+            HostTensor t;
+            t.data = out.storage.back().data();
+            t.shape = v.shape;
+            out.sd[base + ".weight"] = t;
+        } else if (!ends(".weight_v")) {
+            out.sd[k] = kv.second;
+        }
+    }
+}
+}  // namespace
+
+struct Vocoder::Impl {
+    maa_vocoder_config cfg;
+    WeightStore ws;
+    PackedW conv_pre, conv_post;
+    std::vector<UpW> ups;
+    std::vector<ResBlockW> rbs;
+    float *post_alpha = nullptr, *post_inv_beta = nullptr;
+    int hop = 1;
+
+    void snake_params(const StateDict& sd, const std::string& p, float** alpha, float** inv_beta) {
+        // activations.py:107-119: alpha, beta = exp(param) if logscale; x + 1/(beta + 1e-9) * sin^2(alpha x)
+        const HostTensor& a = get(sd, p + "act.alpha");
+        const HostTensor& b = cfg.snake_beta ? get(sd, p + "act.beta") : a;
+        std::vector<float> ha((size_t)a.numel()), hb((size_t)a.numel());
+        for (long long i = 0; i < a.numel(); ++i) {
+            float av = a.data[i], bv = b.data[i];
+            if (cfg.snake_logscale) {
+                av = std::exp(av);
+                bv = std::exp(bv);
+            }
+            ha[(size_t)i] = av;
+            hb[(size_t)i] = 1.0f / (bv + 1e-9f);
+        }
+        *alpha = ws.upload(ha);
+        *inv_beta = ws.upload(hb);
+    }
+
+    void build(const StateDict& raw) {
+        Folded f;
+        fold_weight_norm(raw, f);
+        const StateDict& sd = f.sd;
+        const bool big = cfg.kind == 1;
+        conv_pre = ws.pack_conv(sd, "conv_pre.weight", "conv_pre.bias", 1, 7);
+        int ch = cfg.upsample_initial_channel;
+        for (int i = 0; i < cfg.n_upsamples; ++i) {
+            const std::string name = big ? "ups." + std::to_string(i) + ".0" : "ups." + std::to_string(i);
+            UpW u;
+            u.stride = cfg.upsample_rates[i];
+            u.k = cfg.upsample_kernel_sizes[i];
+            u.cin = ch;
+            u.cout = ch / 2;
+            const int pad = (u.k - u.stride) / 2;
+            for (int carry = 0; carry < 2; ++carry) {
+                bool any = false;
+                for (int r = 0; r < u.stride; ++r) any = any || ((r + pad) / u.stride == carry);
+                if (!any) continue;
+                u.ph[u.n_groups] = ws.pack_convtr_phase(sd, name + ".weight", name + ".bias", u.stride, pad, carry,
+                                                        &u.r_start[u.n_groups], &u.r_count[u.n_groups]);
+                // remember the carry in r_start's sign-free companion: recomputed at run time from r_start
+                ++u.n_groups;
+            }
+            ups.push_back(u);
+            ch /= 2;
+            hop *= u.stride;
+            for (int j = 0; j < cfg.n_kernels; ++j) {
+                const std::string p = "resblocks." + std::to_string(i * cfg.n_kernels + j) + ".";
+                ResBlockW rb;
+                for (int m = 0; m < cfg.n_dilations; ++m) {
+                    ConvK a, b;
+                    a.k = b.k = cfg.resblock_kernel_sizes[j];
+                    a.dil = cfg.resblock_dilation_sizes[j][m];
+                    b.dil = 1;
+                    a.w = ws.pack_conv(sd, p + "convs1." + std::to_string(m) + ".weight",
+                                       p + "convs1." + std::to_string(m) + ".bias", 1, a.k);
+                    b.w = ws.pack_conv(sd, p + "convs2." + std::to_string(m) + ".weight",
+                                       p + "convs2." + std::to_string(m) + ".bias", 1, b.k);
+                    rb.c1.push_back(a);
+                    rb.c2.push_back(b);
+                    if (big) {
+                        for (int q = 0; q < 2; ++q) {
+                            float *al, *ib;
+                            snake_params(sd, p + "activations." + std::to_string(2 * m + q) + ".", &al, &ib);
+                            rb.alpha.push_back(al);
+                            rb.inv_beta.push_back(ib);
+                        }
+                    }
+                }
+                rbs.push_back(rb);
+            }
+        }
+        if (big) snake_params(sd, "activation_post.", &post_alpha, &post_inv_beta);
+        conv_post = ws.pack_conv(sd, "conv_post.weight", "conv_post.bias", 1, 7);
+    }
+
+    // dilated "same" conv1d on [B, L, C]
+    void conv1d(Ctx& ctx, const T4& x, const ConvK& c, float leaky, const float* res, float out_scale, int accumulate,
+                T4& out) {
+        ConvOpt o;
+        o.KH = 1;
+        o.KW = c.k;
+        o.dil = c.dil;
+        o.pad = (c.k * c.dil - c.dil) / 2;
+        o.pad_h = 0;
+        if (leaky != 0.f) {
+            o.a_act = 1;
+            o.a_slope = leaky;
+        }
+        o.res = res;
+        o.out_scale = out_scale;
+        o.accumulate = accumulate;
+        conv_into(ctx, x, nullptr, c.w, o, out);
+    }
+
+    void forward(Ctx& ctx, const float* mel, int B, int T, float* wav) {
+        const bool big = cfg.kind == 1;
+        T4 m = alloc_t(ctx, B, 1, T, cfg.num_mels);
+        launch_nchw_to_nhwc(ctx, mel, B, cfg.num_mels, T, m.p);
+        T4 x = alloc_t(ctx, B, 1, T, cfg.upsample_initial_channel);
+        {
+            ConvOpt o;
+            o.KW = 7;
+            o.pad = 3;
+            o.pad_h = 0;
+            conv_into(ctx, m, nullptr, conv_pre, o, x);
+        }
+        int L = T;
+        for (size_t i = 0; i < ups.size(); ++i) {
+            const UpW& u = ups[i];
+            const int Lo = L * u.stride;
+            T4 y = alloc_t(ctx, B, 1, Lo, u.cout);
+            const int U = u.k / u.stride, pad = (u.k - u.stride) / 2;
+            for (int gi = 0; gi < u.n_groups; ++gi) {
+                // polyphase group: rows j of [B*L] produce output rows s*j + r, r in [r_start, r_start + r_count)
+                const int carry = (u.r_start[gi] + pad) / u.stride;
+                IGemm p;
+                p.a1 = x.p;
+                p.lda1 = u.cin;
+                p.C1 = u.cin;
+                p.Hin = 1;
+                p.Win = L;
+                p.Hout = 1;
+                p.Wout = L;
+                p.KH = 1;
+                p.KW = U;
+                p.pw = U - 1 - carry;
+                if (!big) {                       // hifigan.py:153 leaky before ups; BigVGAN has none (models.py:185-188)
+                    p.a_act = 1;
+                    p.a_slope = 0.1f;
+                }
+                p.b = u.ph[gi].w;
+                p.ldb = u.ph[gi].Npad;
+                p.M = B * L;
+                p.K = U * u.cin;
+                p.N = u.r_count[gi] * u.cout;
+                p.bias = u.ph[gi].bias;
+                p.c = y.p + (long long)u.r_start[gi] * u.cout;
+                p.ldc = u.stride * u.cout;
+                launch_igemm(ctx, p);
+            }
+            L = Lo;
+            // MRF: x = (rb_0(y) + rb_1(y) + rb_2(y)) / n on the SAME input (hifigan.py:158-164)
+            T4 xs = alloc_t(ctx, B, 1, L, u.cout);
+            const size_t mk = ctx.ws.mark();
+            const float inv_n = 1.0f / (float)cfg.n_kernels;
+            for (int j = 0; j < cfg.n_kernels; ++j) {
+                const ResBlockW& rb = rbs[i * cfg.n_kernels + j];
+                T4 cur = y;
+                T4 t1 = alloc_t(ctx, B, 1, L, u.cout);
+                T4 bufA = alloc_t(ctx, B, 1, L, u.cout), bufB = alloc_t(ctx, B, 1, L, u.cout);
+                T4 act = big ? alloc_t(ctx, B, 1, L, u.cout) : T4();
+                for (size_t mth = 0; mth < rb.c1.size(); ++mth) {
+                    const bool last = mth + 1 == rb.c1.size();
+                    // xt = c1(act(x)); xt = c2(act(xt)); x = xt + x      (hifigan.py:54-61 / bigvgan models.py:72-81)
+                    if (big) {
+                        launch_snake_aa(ctx, cur.p, B, L, u.cout, rb.inv_beta[2 * mth], rb.alpha[2 * mth], act.p);
+                        conv1d(ctx, act, rb.c1[mth], 0.f, nullptr, 1.f, 0, t1);
+                        launch_snake_aa(ctx, t1.p, B, L, u.cout, rb.inv_beta[2 * mth + 1], rb.alpha[2 * mth + 1], act.p);
+                    } else {
+                        conv1d(ctx, cur, rb.c1[mth], 0.1f, nullptr, 1.f, 0, t1);
+                    }
+                    const T4& in2 = big ? act : t1;
+                    const float lk2 = big ? 0.f : 0.1f;
+                    if (last) {
+                        conv1d(ctx, in2, rb.c2[mth], lk2, cur.p, inv_n, j > 0, xs);
+                    } else {
+                        T4& dst = (cur.p == bufA.p) ? bufB : bufA;
+                        conv1d(ctx, in2, rb.c2[mth], lk2, cur.p, 1.f, 0, dst);
+                        cur = dst;
+                    }
+                }
+                ctx.ws.release(mk);
+            }
+            x = xs;
+        }
+        // final activation (leaky slope 0.01, hifigan.py:165 / activation_post, bigvgan models.py:199), conv_post, tanh
+        T4 w;            // [B, L, 1] is the caller's [B, L] wave buffer
+        w.B = B;
+        w.H = 1;
+        w.W = L;
+        w.C = 1;
+        w.p = wav;
+        ConvOpt o;
+        o.KW = 7;
+        o.pad = 3;
+        o.pad_h = 0;
+        o.act = 1;
+        if (big) {
+            T4 act = alloc_t(ctx, B, 1, L, x.C);
+            launch_snake_aa(ctx, x.p, B, L, x.C, post_inv_beta, post_alpha, act.p);
+            conv_into(ctx, act, nullptr, conv_post, o, w);
+        } else {
+            o.a_act = 1;
+            o.a_slope = 0.01f;
+            conv_into(ctx, x, nullptr, conv_post, o, w);
+        }
+    }
+};
+
+Vocoder::Vocoder(const maa_vocoder_config& cfg, const StateDict& sd) : impl_(new Impl) {
+    impl_->cfg = cfg;
+    impl_->build(sd);
+}
+Vocoder::~Vocoder() { delete impl_; }
+int Vocoder::hop() const { return impl_->hop; }
+
+void Vocoder::forward(Ctx& ctx, const float* mel, int B, int T, float* wav) {
+    run_sized(ctx, [&] { impl_->forward(ctx, mel, B, T, wav); });
+}
+
+}  // namespace maa

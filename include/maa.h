@@ -1,0 +1,187 @@
+/* libaudiogpt_mi355x -- C ABI of the MI355X-native Make-An-Audio generation backend.
+ *
+ * The reference (AIGC-Audio/AudioGPT) is pure Python/PyTorch and has NO FFI / plugin layer for this path
+ * (SURVEY.md 8b): what this header replaces are the Python methods the tool classes call.  Each entry
+ * point names the reference interface it stands in for; `INTEGRATION.md` shows the ctypes binding a
+ * maintainer adds on the reference side (audiogpt_amd/_lib.py is that binding, shipped).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative maa_status otherwise; maa_last_error() returns a
+ *     thread-local message.  No C++ exception crosses the boundary.
+ *   - tensors are plain pointers + sizes.  Device pointers are fp32 and live on the context's device;
+ *     the caller owns every buffer, the library owns only the opaque handles.
+ *   - tensor layouts at the boundary are the reference's: images NCHW, mels [B, n_mels, T], waves [B, T*hop],
+ *     cross-attention context [B, L, context_dim].  (Inside, activations are channels-last.)
+ *   - all launches are asynchronous on the context's HIP stream; only maa_ctx_synchronize blocks.
+ *   - one context per (device, stream); calls on one context must be serialised by the caller
+ *     (the reference's DDIMSampler is not re-entrant either: ddim.py:27-56 re-registers buffers per call).
+ *   - weights are passed as HOST pointers in the reference's state_dict layout (names + shapes + fp32 data);
+ *     the library repacks them for its kernels and uploads them.
+ */
+#ifndef MAA_H_
+#define MAA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum maa_status {
+    MAA_OK = 0,
+    MAA_ERR_INVALID = -1,   /* bad argument / shape / missing weight */
+    MAA_ERR_HIP = -2,       /* HIP runtime failure */
+    MAA_ERR_INTERNAL = -3
+} maa_status;
+
+typedef struct maa_ctx maa_ctx;         /* device + stream + workspace */
+typedef struct maa_unet maa_unet;       /* UNetModel weights + plan */
+typedef struct maa_vae maa_vae;         /* AutoencoderKL decoder (+ encoder) */
+typedef struct maa_vocoder maa_vocoder; /* HiFi-GAN / BigVGAN generator */
+
+/* thread-local message of the last failing call on this thread */
+const char* maa_last_error(void);
+/* "libaudiogpt_mi355x <version> gfx950" */
+const char* maa_version(void);
+
+/* ---- context ------------------------------------------------------------------------------------
+ * stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for the default stream. */
+int maa_ctx_create(int device_id, void* hip_stream, maa_ctx** out);
+int maa_ctx_destroy(maa_ctx* ctx);
+int maa_ctx_synchronize(maa_ctx* ctx);
+int maa_ctx_set_stream(maa_ctx* ctx, void* hip_stream);
+/* bytes currently reserved for the activation workspace */
+int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out);
+
+/* one named fp32 host tensor of a reference state_dict */
+typedef struct maa_tensor {
+    const char* name;        /* e.g. "input_blocks.1.0.in_layers.2.weight" */
+    const float* data;       /* host pointer, contiguous */
+    int ndim;
+    int64_t shape[6];
+} maa_tensor;
+
+/* ---- UNet ---------------------------------------------------------------------------------------
+ * Mirrors the constructor arguments of ldm.modules.diffusionmodules.openaimodel.UNetModel
+ * (openaimodel.py:443-470) as used by the three shipped configs (txt2audio_args.yaml:31-50,
+ * img2audio_args.yaml:31-49, inpaint/txt2audio_args.yaml:30-45). */
+typedef struct maa_unet_config {
+    int in_channels, out_channels, model_channels;
+    int num_res_blocks;
+    int n_channel_mult, channel_mult[8];
+    int n_attention_resolutions, attention_resolutions[8];
+    int num_heads, num_head_channels;          /* -1 = unset, as in the reference */
+    int use_spatial_transformer, transformer_depth, context_dim;
+    int legacy, resblock_updown;
+    int add_context_to_emb;                    /* custom_openaimodel.py:352-354 (I2A) */
+} maa_unet_config;
+
+/* replaces: instantiate_from_config(unet_config) + load_state_dict (audio-chatgpt.py:147-152);
+ * tensors: the `model.diffusion_model.`-relative entries of the checkpoint */
+int maa_unet_create(maa_ctx* ctx, const maa_unet_config* cfg, const maa_tensor* tensors, int n_tensors,
+                    maa_unet** out);
+int maa_unet_destroy(maa_unet* u);
+/* Cross-attention context for the following forwards: d_context [B, L, context_dim] (device).  The K/V
+ * projections of every transformer block are computed here, once, and reused by each forward -- the
+ * context is constant over a DDIM trajectory (ddim.py:177-198 rebuilds c_in from the same c/uc every step). */
+int maa_unet_set_context(maa_ctx* ctx, maa_unet* u, const float* d_context, int B, int L);
+/* replaces: UNetModel.forward(x, timesteps, context) (openaimodel.py:711-744 / custom_openaimodel.py:331-368)
+ * d_x [B, Cin, H, W], d_t [B] (timesteps as fp32), d_out [B, Cout, H, W].  For the I2A variant the
+ * context passed to set_context is also added to the time embedding. */
+int maa_unet_forward(maa_ctx* ctx, maa_unet* u, const float* d_x, const float* d_t, int B, int H, int W,
+                     float* d_out);
+
+/* ---- DDIM ---------------------------------------------------------------------------------------
+ * replaces: DDIMSampler.p_sample_ddim's elementwise tail (ddim.py:199, 210-225), eta = 0 or with caller noise:
+ *   e = eu + scale*(ec - eu) (ec may be NULL: no guidance);  x0 = (x - sqrt(1-a_t) e)/sqrt(a_t);
+ *   x_prev = sqrt(a_prev) x0 + sqrt(1 - a_prev - sigma^2) e
+ * d_coef: device float[4] = {a_t, a_prev, sigma_t, sqrt(1-a_t)} exactly as the sampler's fp32 tables hold them. */
+int maa_ddim_update(maa_ctx* ctx, const float* d_x, const float* d_eps_uncond, const float* d_eps_cond, float scale,
+                    const float* d_coef, int64_t n, float* d_x_prev, float* d_pred_x0);
+
+/* replaces: DDIMSampler.ddim_sampling (ddim.py:118-166) for the tools' call pattern (eta = 0, no mask):
+ * runs S steps on the device without host round trips.
+ *   d_x [B, C, H, W] in/out latent (x_T in, x_0 out)
+ *   d_cond / d_uncond [B, L, context_dim] (crossattn; d_uncond NULL or scale == 1 -> no CFG), or for the
+ *   concat-conditioned inpaint model d_concat [B, Cc, H, W] (cat([x, c]) -> UNet, ddpm.py:1404-1406)
+ *   h_timesteps [S] (ascending DDIM timesteps), h_alphas / h_alphas_prev [S] fp32 tables (host) */
+typedef struct maa_ddim_args {
+    int S, B, C, H, W;
+    float scale;
+    const float* d_cond;
+    const float* d_uncond;
+    int L;
+    const float* d_concat;
+    int Cc;
+    const int32_t* h_timesteps;
+    const float* h_alphas;
+    const float* h_alphas_prev;
+    int use_graph;          /* capture one step into a hipGraph and replay it */
+} maa_ddim_args;
+int maa_ddim_sample(maa_ctx* ctx, maa_unet* u, const maa_ddim_args* args, float* d_x);
+
+/* ---- VAE ----------------------------------------------------------------------------------------
+ * ddconfig of ldm.models.autoencoder.AutoencoderKL (txt2audio_args.yaml:54-68) */
+typedef struct maa_vae_config {
+    int ch, out_ch, in_channels, z_channels, embed_dim, resolution, num_res_blocks, double_z;
+    int n_ch_mult, ch_mult[8];
+    int n_attn_resolutions, attn_resolutions[8];
+} maa_vae_config;
+/* tensors: the `first_stage_model.`-relative entries (decoder.*, post_quant_conv.*; encoder.*, quant_conv.* optional) */
+int maa_vae_create(maa_ctx* ctx, const maa_vae_config* cfg, const maa_tensor* tensors, int n_tensors, maa_vae** out);
+int maa_vae_destroy(maa_vae* v);
+/* replaces: LatentDiffusion_audio.decode_first_stage (ddpm_audio.py:352-359) -> AutoencoderKL.decode
+ * (autoencoder.py:351-354): d_z [B, 4, h, w] -> d_mel [B, out_ch, 8h, 8w]; inv_scale = 1/scale_factor */
+int maa_vae_decode(maa_ctx* ctx, maa_vae* v, const float* d_z, int B, int h, int w, float inv_scale, float* d_mel);
+/* replaces: AutoencoderKL.encode's moments (autoencoder.py:345-349): d_mel [B, 1, H, W] ->
+ * d_moments [B, 2*embed_dim, H/8, W/8] = (mean | logvar, unclamped) */
+int maa_vae_encode_moments(maa_ctx* ctx, maa_vae* v, const float* d_mel, int B, int H, int W, float* d_moments);
+
+/* ---- vocoder ------------------------------------------------------------------------------------ */
+typedef struct maa_vocoder_config {
+    int kind;                      /* 0 HiFi-GAN (leaky-ReLU MRF), 1 BigVGAN (anti-aliased snake MRF) */
+    int num_mels, upsample_initial_channel;
+    int n_upsamples, upsample_rates[8], upsample_kernel_sizes[8];
+    int n_kernels, resblock_kernel_sizes[8];
+    int n_dilations, resblock_dilation_sizes[8][8];
+    int snake_beta, snake_logscale; /* BigVGAN: activation == "snakebeta", snake_logscale */
+} maa_vocoder_config;
+/* tensors: generator state_dict (weight_g/weight_v pairs or folded `weight`), keys as
+ * NeuralSeq/modules/hifigan/hifigan.py:104-142 / vocoder/bigvgan/models.py:133-179 */
+int maa_vocoder_create(maa_ctx* ctx, const maa_vocoder_config* cfg, const maa_tensor* tensors, int n_tensors,
+                       maa_vocoder** out);
+int maa_vocoder_destroy(maa_vocoder* v);
+/* replaces: HifiGanGenerator.forward(x, f0=None) (hifigan.py:144-169), Generator.forward
+ * (vocoder/hifigan/modules.py:111-127), BigVGAN.forward (bigvgan/models.py:181-203):
+ * d_mel [B, num_mels, T] -> d_wav [B, T*hop] */
+int maa_vocoder_forward(maa_ctx* ctx, maa_vocoder* v, const float* d_mel, int B, int T, float* d_wav);
+
+/* ---- single-operator entry points (parity tests and profiling of individual kernels) ------------ */
+/* y[M,N] = A[M,K] * W^T (+bias) with W given as torch Linear weight [N,K] on the HOST; A, y on device */
+int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w, const float* h_bias, int N,
+                  int geglu, float* d_y);
+/* conv on channels-first tensors: d_x [B,Cin,H,W] (1-D: H = 1), torch weight [Cout,Cin,KH,KW] on the HOST */
+int maa_op_conv(maa_ctx* ctx, const float* d_x, int B, int Cin, int H, int W, const float* h_w, const float* h_bias,
+                int Cout, int KH, int KW, int stride, int pad, int dil, int upsample2, float leaky_slope,
+                float* d_y, int Ho, int Wo);
+/* GroupNorm(32 groups)(+SiLU) on d_x [B,C,HW] */
+int maa_op_groupnorm(maa_ctx* ctx, const float* d_x, int B, int C, int HW, const float* h_gamma,
+                     const float* h_beta, float eps, int silu, float* d_y);
+/* LayerNorm over the last dim of d_x [rows, C] */
+int maa_op_layernorm(maa_ctx* ctx, const float* d_x, int rows, int C, const float* h_gamma, const float* h_beta,
+                     float eps, float* d_y);
+/* softmax(alpha * q k^T) v per head; q [B,Nq,heads*dh], k/v [B,Nk,heads*dh] -> y [B,Nq,heads*dh] */
+int maa_op_attention(maa_ctx* ctx, const float* d_q, const float* d_k, const float* d_v, int B, int heads, int dh,
+                     int Nq, int Nk, float alpha, float* d_y);
+/* ConvTranspose1d, d_x [B,Cin,L], torch weight [Cin,Cout,k] on the HOST, padding (k-stride)/2 -> [B,Cout,L*stride] */
+int maa_op_conv_transpose1d(maa_ctx* ctx, const float* d_x, int B, int Cin, int L, const float* h_w,
+                            const float* h_bias, int Cout, int k, int stride, float leaky_slope, float* d_y);
+/* BigVGAN Activation1d (up2 FIR -> snake(beta) -> down2 FIR) on d_x [B,C,L] */
+int maa_op_snake_aa(maa_ctx* ctx, const float* d_x, int B, int C, int L, const float* h_alpha, const float* h_beta,
+                    int logscale, float* d_y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAA_H_ */

@@ -1,0 +1,170 @@
+"""Model-level parity of the HIP path (through the C ABI) against the reference-generated golden
+vectors (tests/golden, made by the reference's own modules) and against the CPU oracle.
+
+Stated tolerances (fp32 path): UNet eps rel-max 1e-4; 10-step DDIM latent rel-max 1e-3; mel-L1 on the
+[0,1] mel <= 1e-4; waveform RMS error <= 1e-4 of full scale."""
+import numpy as np
+import pytest
+import torch
+
+from audiogpt_amd import config as C
+from audiogpt_amd import weights as WT
+from tests.util import check, record, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from audiogpt_amd.backend import Context
+    c = Context("cuda:0")
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def unet_t2a(ctx):
+    from audiogpt_amd.backend import UNet
+    return UNet(ctx, C.UNET_T2A, WT.make_unet_state_dict(C.UNET_T2A, seed=0))
+
+
+@pytest.fixture(scope="module")
+def vae(ctx):
+    from audiogpt_amd.backend import VAE
+    return VAE(ctx, C.VAE_DDCONFIG, WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1))
+
+
+def _ddim_tables(S, ldm):
+    from oracle import ddim as O
+    ac = O.alphas_cumprod(ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+    steps = O.ddim_timesteps(S, ldm["timesteps"])
+    a, ap, _, _ = O.ddim_tables(ac, steps)
+    return steps, a.numpy(), ap.numpy()
+
+
+def test_unet_t2a_matches_reference(golden, unet_t2a):
+    g = golden("unet_t2a")
+    y = unet_t2a(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"]))
+    check("unet_t2a_vs_reference", y, g["y"], 1e-4)
+
+
+def test_unet_batch_invariance(golden, unet_t2a):
+    """Sharding prompts over GPUs must not change results: sample i of a batch == the same sample alone."""
+    g = golden("unet_t2a")
+    x, t, c = torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"])
+    xb = torch.cat([x, x.flip(0), x]), torch.cat([t, t.flip(0), t]), torch.cat([c, c.flip(0), c])
+    yb = unet_t2a(*xb).cpu()
+    y1 = unet_t2a(x[1:2], t[1:2], c[1:2]).cpu()
+    assert torch.equal(yb[1:2], y1) and torch.equal(yb[2:3], y1), "UNet output depends on batch composition"
+
+
+@pytest.mark.parametrize("name,cfg,seed", [("unet_i2a", C.UNET_I2A, 4), ("unet_inpaint", C.UNET_INPAINT, 5)])
+def test_unet_variants_match_reference(golden, ctx, name, cfg, seed):
+    from audiogpt_amd.backend import UNet
+    g = golden(name)
+    u = UNet(ctx, cfg, WT.make_unet_state_dict(cfg, seed=seed))
+    c = torch.from_numpy(g["context"]) if "context" in g else None
+    y = u(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), c)
+    check(name + "_vs_reference", y, g["y"], 1e-4)
+    u.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_ddim_10_steps_matches_reference(golden, unet_t2a, use_graph):
+    g = golden("ddim_t2a_s10")
+    steps, a, ap = _ddim_tables(int(g["S"]), C.LDM_T2A)
+    assert steps.tolist() == g["ddim_timesteps"].tolist()
+    z = unet_t2a.ddim_sample(torch.from_numpy(g["x_T"]), steps, a, ap, cond=torch.from_numpy(g["c"]),
+                             uncond=torch.from_numpy(g["uc"]), scale=float(g["scale"]), use_graph=use_graph)
+    check(f"ddim_s10_graph{int(use_graph)}_vs_reference", z, g["z"], 1e-3)
+
+
+def test_ddim_graph_replay_is_bit_identical(golden, unet_t2a):
+    g = golden("ddim_t2a_s10")
+    steps, a, ap = _ddim_tables(6, C.LDM_T2A)
+    args = dict(cond=torch.from_numpy(g["c"]), uncond=torch.from_numpy(g["uc"]), scale=1.5)
+    z0 = unet_t2a.ddim_sample(torch.from_numpy(g["x_T"]), steps, a, ap, use_graph=False, **args).cpu()
+    z1 = unet_t2a.ddim_sample(torch.from_numpy(g["x_T"]), steps, a, ap, use_graph=True, **args).cpu()
+    assert torch.equal(z0, z1)
+
+
+def test_vae_decode_and_encode_match_reference(golden, vae):
+    g = golden("vae")
+    mel = vae.decode(torch.from_numpy(g["z"]), 1.0)
+    check("vae_decode_vs_reference", mel, g["mel"], 2e-4)
+    m01 = torch.clamp((mel.cpu() + 1) / 2, 0, 1)
+    r01 = torch.clamp((torch.from_numpy(g["mel"]) + 1) / 2, 0, 1)
+    l1 = float((m01 - r01).abs().mean())
+    record("vae_mel_l1", mel_l1=l1, tol=1e-4)
+    assert l1 <= 1e-4
+    mom = vae.encode_moments(torch.from_numpy(g["mel_in"]))
+    check("vae_encode_vs_reference", mom, g["moments"], 2e-4)
+
+
+@pytest.mark.parametrize("name,cfg", [("hifigan_16k_t2a", C.HIFIGAN_16K), ("hifigan_ns512", C.HIFIGAN_NS_512),
+                                      ("hifigan_ns128", C.HIFIGAN_NS_128)])
+def test_hifigan_matches_reference(golden, ctx, name, cfg):
+    from audiogpt_amd.backend import Vocoder
+    g = golden(name)
+    v = Vocoder(ctx, cfg, WT.make_vocoder_state_dict(cfg, seed=2))
+    wav = v(torch.from_numpy(g["mel"])).cpu()
+    ref = torch.from_numpy(g["wav"])
+    rms = float(((wav - ref) ** 2).mean().sqrt())
+    record(name + "_wav_rms", wav_rms=rms, tol=1e-4)
+    check(name + "_vs_reference", wav, ref, 2e-4)
+    assert rms <= 1e-4
+    v.close()
+
+
+def test_bigvgan_matches_reference(golden, ctx):
+    from audiogpt_amd.backend import Vocoder
+    g = golden("bigvgan_16k")
+    v = Vocoder(ctx, C.BIGVGAN_16K, WT.make_vocoder_state_dict(C.BIGVGAN_16K, seed=3))
+    wav = v(torch.from_numpy(g["mel"])).cpu()
+    ref = torch.from_numpy(g["wav"])
+    rms = float(((wav - ref) ** 2).mean().sqrt())
+    record("bigvgan_wav_rms", wav_rms=rms, tol=1e-4)
+    check("bigvgan_vs_reference", wav, ref, 5e-4)
+    assert rms <= 1e-4
+    v.close()
+
+
+def test_t2a_plumbing_config1_end_to_end(golden, ctx, unet_t2a, vae):
+    """BASELINE config 1: 1 prompt, 10 DDIM steps, CFG 1.5 -> VAE -> clamp -> HiFi-GAN, vs the reference chain."""
+    from audiogpt_amd.backend import Vocoder
+    g = golden("ddim_t2a_s10")
+    steps, a, ap = _ddim_tables(10, C.LDM_T2A)
+    z = unet_t2a.ddim_sample(torch.from_numpy(g["x_T"]), steps, a, ap, cond=torch.from_numpy(g["c"]),
+                             uncond=torch.from_numpy(g["uc"]), scale=1.5)
+    mel = vae.decode(z, 1.0)
+    spec = torch.clamp((mel + 1.0) / 2.0, 0.0, 1.0)[:, 0]
+    ref_spec = torch.from_numpy(golden("hifigan_16k_t2a")["mel"])
+    l1 = float((spec.cpu() - ref_spec).abs().mean())
+    record("t2a_config1_mel_l1", mel_l1=l1, tol=1e-4)
+    assert l1 <= 1e-4, f"mel-L1 {l1:.3e}"
+    v = Vocoder(ctx, C.HIFIGAN_16K, WT.make_vocoder_state_dict(C.HIFIGAN_16K, seed=2))
+    wav = v(spec).cpu()
+    ref = torch.from_numpy(golden("hifigan_16k_t2a")["wav"])
+    rms = float(((wav - ref) ** 2).mean().sqrt())
+    record("t2a_config1_wav_rms", wav_rms=rms, tol=1e-4)
+    assert rms <= 1e-4, f"waveform RMS error {rms:.3e}"
+    v.close()
+
+
+def test_vocoder_batch_invariance_and_ragged_lengths(ctx):
+    """Edge cases: T not a multiple of any tile, batch rows independent."""
+    from audiogpt_amd.backend import Vocoder
+    from oracle import vocoder as O
+    cfg = C.HIFIGAN_NS_128
+    sd = WT.make_vocoder_state_dict(cfg, seed=2)
+    v = Vocoder(ctx, cfg, sd)
+    gen = torch.Generator().manual_seed(11)
+    for T in (1, 7, 33):
+        mel = torch.randn(3, 80, T, generator=gen)
+        wav = v(mel).cpu()
+        with torch.no_grad():
+            ref = O.hifigan_forward(O.fold_weight_norm(sd), cfg, mel)
+        check(f"hifigan_T{T}", wav, ref, 2e-4)
+        one = v(mel[2:3]).cpu()
+        assert torch.equal(one, wav[2:3])
+    v.close()
