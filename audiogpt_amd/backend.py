@@ -28,10 +28,12 @@ class Context:
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", idx)
         torch.cuda.set_device(idx)
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        self._stream = s
+        # stream=None: the library creates its own (blocking) HIP stream, which orders against PyTorch's
+        # default stream and can be captured into a hipGraph; pass a torch.cuda.Stream to share one.
+        self._stream = stream
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else None
         h = C.c_void_p()
-        L.check(self.lib.maa_ctx_create(idx, C.c_void_p(s.cuda_stream), C.byref(h)))
+        L.check(self.lib.maa_ctx_create(idx, sp, C.byref(h)))
         self.h = h
         self.lock = threading.RLock()
 
@@ -42,6 +44,18 @@ class Context:
         n = C.c_size_t()
         L.check(self.lib.maa_ctx_workspace_bytes(self.h, C.byref(n)))
         return n.value
+
+    def prof_begin(self):
+        """Start per-kernel hipEvent timing of every launch on this context (eager launches only)."""
+        L.check(self.lib.maa_prof_begin(self.h))
+
+    def prof_end(self):
+        """Stop timing; returns {kernel: dict(launches, ms, flops, bytes)}."""
+        rows = (L.maa_prof_row * 64)()
+        n = C.c_int()
+        L.check(self.lib.maa_prof_end(self.h, rows, 64, C.byref(n)))
+        return {rows[i].name.decode(): dict(launches=int(rows[i].launches), ms=rows[i].ms, flops=rows[i].flops,
+                                            bytes=rows[i].bytes) for i in range(n.value)}
 
     def close(self):
         if getattr(self, "h", None):

@@ -11,6 +11,7 @@ const char* last_error_cstr();
 
 struct maa_ctx {
     maa::Ctx c;
+    bool owns_stream = false;
 };
 struct maa_unet {
     std::unique_ptr<maa::UNet> m;
@@ -88,7 +89,20 @@ int maa_ctx_create(int device_id, void* hip_stream, maa_ctx** out) {
         MAA_HIP(hipSetDevice(device_id));
         auto* c = new maa_ctx;
         c->c.device = device_id;
-        c->c.stream = static_cast<hipStream_t>(hip_stream);
+        if (hip_stream) {
+            c->c.stream = static_cast<hipStream_t>(hip_stream);
+        } else {
+            // own stream, created WITHOUT hipStreamNonBlocking: it orders against the legacy default stream
+            // (where PyTorch-ROCm puts its copies), and unlike the default stream it can be graph-captured
+            hipStream_t s = nullptr;
+            hipError_t e = hipStreamCreate(&s);
+            if (e != hipSuccess) {
+                delete c;
+                throw maa::Error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+            }
+            c->c.stream = s;
+            c->owns_stream = true;
+        }
         *out = c;
     });
 }
@@ -97,6 +111,7 @@ int maa_ctx_destroy(maa_ctx* ctx) {
         if (!ctx) return;
         (void)hipSetDevice(ctx->c.device);
         (void)hipStreamSynchronize(ctx->c.stream);
+        if (ctx->owns_stream) (void)hipStreamDestroy(ctx->c.stream);
         delete ctx;
     });
 }
@@ -109,6 +124,9 @@ int maa_ctx_synchronize(maa_ctx* ctx) {
 int maa_ctx_set_stream(maa_ctx* ctx, void* hip_stream) {
     return guarded([&] {
         bind(ctx);
+        MAA_CHECK(hip_stream != nullptr, "set_stream needs a non-default stream");
+        if (ctx->owns_stream) (void)hipStreamDestroy(ctx->c.stream);
+        ctx->owns_stream = false;
         ctx->c.stream = static_cast<hipStream_t>(hip_stream);
     });
 }
@@ -116,6 +134,36 @@ int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out) {
     return guarded([&] {
         MAA_CHECK(ctx && out, "null argument");
         *out = ctx->c.ws.capacity();
+    });
+}
+
+int maa_prof_begin(maa_ctx* ctx) {
+    return guarded([&] {
+        bind(ctx);
+        if (!ctx->c.prof) ctx->c.prof = new maa::Profiler;
+        ctx->c.prof->pending.clear();
+        ctx->c.prof->next = 0;
+    });
+}
+int maa_prof_end(maa_ctx* ctx, maa_prof_row* rows, int max_rows, int* n_rows) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(ctx->c.prof && rows && n_rows && max_rows > 0, "prof_end without prof_begin / null output");
+        auto agg = ctx->c.prof->collect(ctx->c.stream);
+        delete ctx->c.prof;
+        ctx->c.prof = nullptr;
+        int n = 0;
+        for (auto& r : agg) {
+            if (n >= max_rows) break;
+            std::memset(&rows[n], 0, sizeof(maa_prof_row));
+            std::strncpy(rows[n].name, r.name.c_str(), sizeof(rows[n].name) - 1);
+            rows[n].launches = r.launches;
+            rows[n].ms = r.ms;
+            rows[n].flops = r.flops;
+            rows[n].bytes = r.bytes;
+            ++n;
+        }
+        *n_rows = n;
     });
 }
 

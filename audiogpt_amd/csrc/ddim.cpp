@@ -94,7 +94,14 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
             } else {
                 if (!exec) {
                     MAA_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeRelaxed));
-                    step_body();
+                    try {
+                        step_body();
+                    } catch (...) {
+                        hipGraph_t dead = nullptr;
+                        (void)hipStreamEndCapture(ctx.stream, &dead);
+                        if (dead) (void)hipGraphDestroy(dead);
+                        throw;
+                    }
                     MAA_HIP(hipStreamEndCapture(ctx.stream, &graph));
                     MAA_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
                 }

@@ -360,24 +360,29 @@ void launch_igemm(const Ctx& ctx, const IGemm& p) {
     } else {
         MAA_CHECK(p.ldb % 4 == 0 && al16(p.b) && p.b_so % 4 == 0 && p.b_si % 4 == 0, "B [N][K] alignment");
     }
+    // algorithmic work of this launch: 2*M*N*K per batch entry (GEGLU computes 2N columns)
+    const double flops = 2.0 * p.M * (double)ncols * p.K * p.Z;
+    const double bytes = 4.0 * ((double)p.K * ncols + (double)p.M * p.N * p.Z);   // weights once + output once
+    int cfg = 0;
     if (p.geglu) {
         MAA_CHECK(ncols % 64 == 0, "geglu needs packed N multiple of 64");
-        launch_cfg<128, 128, 2, 2>(ctx, p, fast_a, Nb);
-        return;
+        cfg = 0;
+    } else if (ncols <= 32) {
+        cfg = 3;
+    } else {
+        const double c128 = tile_cost(p.M, ncols, p.Z, 128, 128, 1.00);
+        const double c12864 = tile_cost(p.M, ncols, p.Z, 128, 64, 0.92);
+        const double c64 = tile_cost(p.M, ncols, p.Z, 64, 64, 0.80);
+        cfg = (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
     }
-    if (ncols <= 32) {
-        launch_cfg<256, 32, 4, 1>(ctx, p, fast_a, Nb);
-        return;
+    static const char* kNames[4] = {"igemm_f32<128x128>", "igemm_f32<128x64>", "igemm_f32<64x64>", "igemm_f32<256x32>"};
+    ProfScope prof(ctx, kNames[cfg], flops, bytes);
+    switch (cfg) {
+        case 0: launch_cfg<128, 128, 2, 2>(ctx, p, fast_a, Nb); break;
+        case 1: launch_cfg<128, 64, 2, 2>(ctx, p, fast_a, Nb); break;
+        case 2: launch_cfg<64, 64, 2, 2>(ctx, p, fast_a, Nb); break;
+        default: launch_cfg<256, 32, 4, 1>(ctx, p, fast_a, Nb); break;
     }
-    const double c128 = tile_cost(p.M, ncols, p.Z, 128, 128, 1.00);
-    const double c12864 = tile_cost(p.M, ncols, p.Z, 128, 64, 0.92);
-    const double c64 = tile_cost(p.M, ncols, p.Z, 64, 64, 0.80);
-    if (c128 <= c12864 && c128 <= c64)
-        launch_cfg<128, 128, 2, 2>(ctx, p, fast_a, Nb);
-    else if (c12864 <= c64)
-        launch_cfg<128, 64, 2, 2>(ctx, p, fast_a, Nb);
-    else
-        launch_cfg<64, 64, 2, 2>(ctx, p, fast_a, Nb);
     MAA_HIP(hipGetLastError());
 }
 

@@ -51,7 +51,37 @@ private:
     size_t cap_ = 0, off_ = 0, high_ = 0, run_high_ = 0;
 };
 
+// Optional per-launch timing (hipEvents on the context's stream).  Off unless maa_prof_begin was called;
+// never active inside a graph capture.
+struct ProfRow {
+    std::string name;
+    long long launches = 0;
+    double ms = 0.0, flops = 0.0, bytes = 0.0;
+};
+class Profiler {
+public:
+    ~Profiler();
+    struct Pending {
+        std::string name;
+        double flops, bytes;
+        hipEvent_t e0, e1;
+    };
+    hipEvent_t get_event();
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    size_t next = 0;
+    std::vector<ProfRow> collect(hipStream_t stream);   // synchronises, aggregates by name, clears
+};
+struct Ctx;
+struct ProfScope {     // records an event pair around the launches issued during its lifetime
+    ProfScope(const Ctx& ctx, const char* name, double flops, double bytes);
+    ~ProfScope();
+    const Ctx* ctx_ = nullptr;
+    size_t idx_ = 0;
+};
+
 struct Ctx {
+    Profiler* prof = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     Arena ws;

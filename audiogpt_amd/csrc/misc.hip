@@ -208,6 +208,7 @@ __global__ void snake_aa_kernel(const float* __restrict__ x, int B, int L, int C
 
 #define MAA_LAUNCH1(kern, n, ...)                                                            \
     if (ctx.ws.dry) return;                                                                  \
+    ProfScope prof(ctx, #kern, 0.0, 8.0 * (double)(n));                                      \
     hipLaunchKernelGGL(kern, grid_for(n), dim3(256), 0, ctx.stream, __VA_ARGS__);            \
     MAA_HIP(hipGetLastError())
 

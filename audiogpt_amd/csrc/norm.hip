@@ -163,6 +163,7 @@ void launch_groupnorm(const Ctx& ctx, const float* x1, int ld1, int C1, const fl
     if (ctx.ws.dry) return;
     const int C = C1 + C2;
     MAA_CHECK(C % groups == 0 && C / groups <= 256, "groupnorm channels");
+    ProfScope prof(ctx, "groupnorm", 0.0, 8.0 * B * (double)HW * C);
     hipLaunchKernelGGL(groupnorm_kernel, dim3(B * groups), dim3(256), 0, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW,
                        groups, gamma, beta, eps, silu, out);
     MAA_HIP(hipGetLastError());
@@ -172,6 +173,7 @@ void launch_layernorm(const Ctx& ctx, const float* x, int rows, int C, const flo
                       float eps, float* out) {
     if (ctx.ws.dry) return;
     MAA_CHECK(C <= 1024, "layernorm width");
+    ProfScope prof(ctx, "layernorm", 0.0, 8.0 * rows * (double)C);
     dim3 grid((rows + 3) / 4);
     if (C <= 320)
         hipLaunchKernelGGL(layernorm_kernel<5>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out);
@@ -185,6 +187,7 @@ void launch_layernorm(const Ctx& ctx, const float* x, int rows, int C, const flo
 void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld) {
     if (ctx.ws.dry) return;
     MAA_CHECK(ld >= cols, "softmax ld");
+    ProfScope prof(ctx, "softmax", 0.0, 8.0 * rows * (double)ld);
     dim3 grid((unsigned)((rows + 3) / 4));
     if (ld <= 128)
         hipLaunchKernelGGL(softmax_kernel<2>, grid, dim3(256), 0, ctx.stream, s, rows, cols, ld);

@@ -37,6 +37,56 @@ float* Arena::alloc_f(size_t n_floats) {
     return reinterpret_cast<float*>(base_ + at);
 }
 
+// ------------------------------------------------------------------------------------------ Profiler
+Profiler::~Profiler() {
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+}
+hipEvent_t Profiler::get_event() {
+    if (next == pool.size()) {
+        hipEvent_t e;
+        MAA_HIP(hipEventCreate(&e));
+        pool.push_back(e);
+    }
+    return pool[next++];
+}
+std::vector<ProfRow> Profiler::collect(hipStream_t stream) {
+    MAA_HIP(hipStreamSynchronize(stream));
+    std::map<std::string, ProfRow> agg;
+    for (auto& p : pending) {
+        float ms = 0.f;
+        MAA_HIP(hipEventElapsedTime(&ms, p.e0, p.e1));
+        ProfRow& r = agg[p.name];
+        r.name = p.name;
+        r.launches += 1;
+        r.ms += ms;
+        r.flops += p.flops;
+        r.bytes += p.bytes;
+    }
+    pending.clear();
+    next = 0;
+    std::vector<ProfRow> out;
+    for (auto& kv : agg) out.push_back(kv.second);
+    return out;
+}
+ProfScope::ProfScope(const Ctx& ctx, const char* name, double flops, double bytes) {
+    if (!ctx.prof || ctx.ws.dry) return;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx.stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
+    ctx_ = &ctx;
+    Profiler::Pending p;
+    p.name = name;
+    p.flops = flops;
+    p.bytes = bytes;
+    p.e0 = ctx.prof->get_event();
+    p.e1 = ctx.prof->get_event();
+    (void)hipEventRecord(p.e0, ctx.stream);
+    idx_ = ctx.prof->pending.size();
+    ctx.prof->pending.push_back(p);
+}
+ProfScope::~ProfScope() {
+    if (ctx_) (void)hipEventRecord(ctx_->prof->pending[idx_].e1, ctx_->stream);
+}
+
 // ------------------------------------------------------------------------------------------ StateDict helpers
 const HostTensor& get(const StateDict& sd, const std::string& name) {
     auto it = sd.find(name);

@@ -1,0 +1,197 @@
+"""AudioGPT tool classes T2A / I2A / Inpaint with the reference's Python call signatures
+(audio-chatgpt.py:140-212, 214-273, 418-558), re-pointed at the MI355X backend.
+
+The LangChain agent binds `Tool(func=<obj>.inference)` (audio-chatgpt.py:1084,1114,1120): a single str in, a
+file name out.  Those signatures are kept byte-compatible; the bodies follow the reference line by line but the
+sampler / model / vocoder objects are the HIP-backed ones.  Reference quirks are reproduced deliberately
+(SURVEY.md section 0.8): `inference()` ignores its seed/scale/ddim_steps/n_samples arguments and calls
+`txt2audio` with the defaults; `Inpaint.inpaint` builds a seeded start_code and does not pass it.
+
+Outside the hot path and therefore pluggable rather than re-implemented:
+  * the conditioning encoders (`model.cond_stage_model`): see ldm/latent_diffusion.py
+  * CLAP best-of-n re-ranking (`select_best_audio`, audio-chatgpt.py:185-199): pass `scorer=`; without one the
+    first sample is returned
+  * wav / image file I/O uses scipy + a minimal PNG/colormap path only if PIL / soundfile are absent
+"""
+import os
+import uuid
+
+import numpy as np
+import torch
+
+from . import config as C
+from .ldm.ddim import DDIMSampler
+from .ldm.latent_diffusion import LatentDiffusionAudio
+from .vocoder.hifigan import VocoderBigVGAN
+
+SAMPLE_RATE = 16000
+
+
+def _write_wav(path, wav, sr):
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    try:
+        import soundfile
+        soundfile.write(path, wav, samplerate=sr)
+    except ImportError:
+        from scipy.io import wavfile
+        wavfile.write(path, sr, np.asarray(wav))
+
+
+class T2A:
+    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, cond_stage_model=None, scorer=None):
+        print("Initializing Make-An-Audio to %s" % device)
+        self.device = device
+        self.sampler = self._initialize_model(C.LDM_T2A, ckpt_state_dict, device, cond_stage_model)
+        self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=self.sampler.model.ctx)
+        self.scorer = scorer
+
+    def _initialize_model(self, config, ckpt, device, cond_stage_model=None):
+        model = LatentDiffusionAudio(config, device=device, state_dict=ckpt, cond_stage_model=cond_stage_model)
+        return DDIMSampler(model)
+
+    def txt2audio(self, text, seed=55, scale=1.5, ddim_steps=100, n_samples=3, W=624, H=80):
+        prng = np.random.RandomState(seed)
+        start_code = prng.randn(n_samples, self.sampler.model.first_stage_model.embed_dim, H // 8, W // 8)
+        start_code = torch.from_numpy(start_code).to(device=self.device, dtype=torch.float32)
+        uc = self.sampler.model.get_learned_conditioning(n_samples * [""])
+        c = self.sampler.model.get_learned_conditioning(n_samples * [text])
+        shape = [self.sampler.model.first_stage_model.embed_dim, H // 8, W // 8]
+        samples_ddim, _ = self.sampler.sample(S=ddim_steps, conditioning=c, batch_size=n_samples, shape=shape,
+                                              verbose=False, unconditional_guidance_scale=scale,
+                                              unconditional_conditioning=uc, x_T=start_code)
+        x_samples_ddim = self.sampler.model.decode_first_stage(samples_ddim)
+        x_samples_ddim = torch.clamp((x_samples_ddim + 1.0) / 2.0, min=0.0, max=1.0)
+        wav_list = []
+        for idx, spec in enumerate(x_samples_ddim):
+            wav = self.vocoder.vocode(spec)
+            wav_list.append((SAMPLE_RATE, wav))
+        return self.select_best_audio(text, wav_list)
+
+    def select_best_audio(self, prompt, wav_list):
+        if self.scorer is None:
+            return wav_list[0]
+        scores = [float(self.scorer(prompt, wav, sr)) for sr, wav in wav_list]
+        return wav_list[int(np.argmax(scores))]
+
+    def inference(self, text, seed=55, scale=1.5, ddim_steps=100, n_samples=3, W=624, H=80):
+        melbins, mel_len = 80, 624
+        with torch.no_grad():
+            result = self.txt2audio(text=text, H=melbins, W=mel_len)
+        audio_filename = os.path.join("audio", str(uuid.uuid4())[0:8] + ".wav")
+        _write_wav(audio_filename, result[1], 16000)
+        print(f"Processed T2I.run, text: {text}, audio_filename: {audio_filename}")
+        return audio_filename
+
+
+class I2A:
+    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, cond_stage_model=None):
+        print("Initializing Make-An-Audio-Image to %s" % device)
+        self.device = device
+        model = LatentDiffusionAudio(C.LDM_I2A, device=device, state_dict=ckpt_state_dict,
+                                     cond_stage_model=cond_stage_model, seeds=(4, 1))
+        self.sampler = DDIMSampler(model)
+        self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=model.ctx)
+
+    def img2audio(self, image, seed=55, scale=3, ddim_steps=100, W=624, H=80):
+        n_samples = 1
+        prng = np.random.RandomState(seed)
+        start_code = prng.randn(n_samples, self.sampler.model.first_stage_model.embed_dim, H // 8, W // 8)
+        start_code = torch.from_numpy(start_code).to(device=self.device, dtype=torch.float32)
+        uc = self.sampler.model.get_learned_conditioning(n_samples * [""])
+        if isinstance(image, str):
+            from PIL import Image
+            image = Image.open(image)
+        image = self.sampler.model.cond_stage_model.preprocess(image).unsqueeze(0)
+        image_embedding = self.sampler.model.cond_stage_model.forward_img(image)
+        c = image_embedding.repeat(n_samples, 1, 1).to(self.device)
+        shape = [self.sampler.model.first_stage_model.embed_dim, H // 8, W // 8]
+        samples_ddim, _ = self.sampler.sample(S=ddim_steps, conditioning=c, batch_size=n_samples, shape=shape,
+                                              verbose=False, unconditional_guidance_scale=scale,
+                                              unconditional_conditioning=uc, x_T=start_code)
+        x_samples_ddim = self.sampler.model.decode_first_stage(samples_ddim)
+        x_samples_ddim = torch.clamp((x_samples_ddim + 1.0) / 2.0, min=0.0, max=1.0)
+        wav_list = []
+        for idx, spec in enumerate(x_samples_ddim):
+            wav_list.append((SAMPLE_RATE, self.vocoder.vocode(spec)))
+        return wav_list[0]
+
+    def inference(self, image, seed=55, scale=3, ddim_steps=100, W=624, H=80):
+        melbins, mel_len = 80, 624
+        with torch.no_grad():
+            result = self.img2audio(image=image, H=melbins, W=mel_len)
+        audio_filename = os.path.join("audio", str(uuid.uuid4())[0:8] + ".wav")
+        _write_wav(audio_filename, result[1], 16000)
+        print(f"Processed I2a.run, image_filename: {image}, audio_filename: {audio_filename}")
+        return audio_filename
+
+
+class Inpaint:
+    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, mel_transform=None):
+        print("Initializing Make-An-Audio-inpaint to %s" % device)
+        self.device = device
+        model = LatentDiffusionAudio(C.LDM_INPAINT, device=device, state_dict=ckpt_state_dict, seeds=(5, 1))
+        self.sampler = DDIMSampler(model)
+        self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=model.ctx)
+        self.mel_transform = mel_transform      # TRANSFORMS_16000 (extract_mel_spectrogram.py:140-150), pluggable
+
+    def make_batch_sd(self, mel, mask, num_samples=1):
+        mel = torch.from_numpy(mel)[None, None, ...].to(dtype=torch.float32)
+        mask = torch.from_numpy(mask)[None, None, ...].to(dtype=torch.float32)
+        masked_mel = (1 - mask) * mel
+        mel = mel * 2 - 1
+        mask = mask * 2 - 1
+        masked_mel = masked_mel * 2 - 1
+        rep = lambda t: t.to(device=self.device).repeat(num_samples, 1, 1, 1)   # noqa: E731
+        return {"mel": rep(mel), "mask": rep(mask), "masked_mel": rep(masked_mel)}
+
+    def inpaint(self, batch, seed, ddim_steps, num_samples=1, W=512, H=512):
+        model = self.sampler.model
+        prng = np.random.RandomState(seed)
+        start_code = prng.randn(num_samples, model.first_stage_model.embed_dim, H // 8, W // 8)
+        start_code = torch.from_numpy(start_code).to(device=self.device, dtype=torch.float32)   # unused, as upstream
+        c = model.get_first_stage_encoding(model.encode_first_stage(batch["masked_mel"]))
+        cc = torch.nn.functional.interpolate(batch["mask"], size=c.shape[-2:])
+        c = torch.cat((c, cc), dim=1)
+        shape = (c.shape[1] - 1,) + c.shape[2:]
+        samples_ddim, _ = self.sampler.sample(S=ddim_steps, conditioning=c, batch_size=c.shape[0], shape=shape,
+                                              verbose=False)
+        x_samples_ddim = model.decode_first_stage(samples_ddim)
+        mel = torch.clamp((batch["mel"] + 1.0) / 2.0, min=0.0, max=1.0)
+        mask = torch.clamp((batch["mask"] + 1.0) / 2.0, min=0.0, max=1.0)
+        predicted_mel = torch.clamp((x_samples_ddim + 1.0) / 2.0, min=0.0, max=1.0)
+        inpainted = (1 - mask) * mel + mask * predicted_mel
+        inpainted = inpainted.cpu().numpy().squeeze()
+        inapint_wav = self.vocoder.vocode(inpainted)
+        return inpainted, inapint_wav
+
+    def inference_mel(self, input_mel, mask, seed=55, ddim_steps=100):
+        """The device part of `inference` (audio-chatgpt.py:539-548) for an [80, 848] mel in [0,1] and a mask."""
+        mel_bins, mel_len = 80, 848
+        input_mel = input_mel[:, :mel_len]
+        mask = np.pad(mask, ((0, 0), (0, mel_len - mask.shape[1])), mode="constant", constant_values=0)
+        with torch.no_grad():
+            batch = self.make_batch_sd(input_mel.astype(np.float32), mask.astype(np.float32), num_samples=1)
+            return self.inpaint(batch=batch, seed=seed, ddim_steps=ddim_steps, num_samples=1, H=mel_bins, W=mel_len)
+
+    def inference(self, input_audio, mel_and_mask, seed=55, ddim_steps=100):
+        if self.mel_transform is None:
+            raise RuntimeError("Inpaint.inference needs the 16 kHz log-mel front end (TRANSFORMS_16000, librosa) "
+                               "passed as mel_transform=; it is outside the accelerated path (SURVEY.md 8f N4)")
+        from PIL import Image
+        torch.set_grad_enabled(False)
+        show_mel = np.array(Image.open(mel_and_mask["image"]).convert("L")) / 255
+        mask = np.array(Image.open(mel_and_mask["mask"]).convert("L")) / 255
+        sr, ori_wav = input_audio
+        input_mel = self.mel_transform(sr, ori_wav)
+        inpainted, gen_wav = self.inference_mel(input_mel, mask, seed, ddim_steps)
+        inpainted = inpainted[:, :show_mel.shape[1]]
+        input_len = int(input_audio[1].shape[0] * SAMPLE_RATE / input_audio[0])
+        gen_wav = (gen_wav * 32768).astype(np.int16)[:input_len]
+        import matplotlib.cm
+        image = Image.fromarray((matplotlib.cm.viridis(inpainted) * 255).astype(np.uint8))
+        image_filename = os.path.join("image", str(uuid.uuid4())[0:8] + ".png")
+        os.makedirs("image", exist_ok=True)
+        image.save(image_filename)
+        audio_filename = os.path.join("audio", str(uuid.uuid4())[0:8] + ".wav")
+        _write_wav(audio_filename, gen_wav, 16000)
+        return image_filename, audio_filename

@@ -54,6 +54,20 @@ int maa_ctx_set_stream(maa_ctx* ctx, void* hip_stream);
 /* bytes currently reserved for the activation workspace */
 int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out);
 
+/* ---- per-kernel timing (replaces the reference's utils.Timer, NeuralSeq/utils/__init__.py:222-237) ----
+ * Between begin and end every kernel launch on this context is bracketed by a hipEvent pair on the context's
+ * stream; end synchronises and returns one row per kernel (aggregated), with the ALGORITHMIC flops / bytes of
+ * the launches.  Launches captured into a hipGraph are not timed (run with use_graph = 0 while profiling). */
+typedef struct maa_prof_row {
+    char name[48];
+    int64_t launches;
+    double ms;       /* sum of launch durations */
+    double flops;    /* sum of algorithmic flops (2*M*N*K for the contractions) */
+    double bytes;    /* sum of algorithmic bytes (compulsory reads + writes) */
+} maa_prof_row;
+int maa_prof_begin(maa_ctx* ctx);
+int maa_prof_end(maa_ctx* ctx, maa_prof_row* rows, int max_rows, int* n_rows);
+
 /* one named fp32 host tensor of a reference state_dict */
 typedef struct maa_tensor {
     const char* name;        /* e.g. "input_blocks.1.0.in_layers.2.weight" */
