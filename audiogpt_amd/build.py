@@ -30,7 +30,25 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+def _source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp")))
+    for f in files + [os.path.join(os.path.dirname(HERE), "include", "maa.h")]:
+        path = f if os.path.isabs(f) else os.path.join(CSRC, f)
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=True):
+    # content-hash stamp: a snapshot copied to the GPU box (fresh mtimes) must not trigger a rebuild there
+    stamp = OUT + ".hash"
+    digest = _source_hash()
+    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        return OUT
     hipcc = _hipcc()
     bdir = os.path.join(CSRC, "_build")
     os.makedirs(bdir, exist_ok=True)
@@ -67,6 +85,8 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed:\n" + r.stderr[-8000:])
         if verbose:
             print("[audiogpt_amd.build] wrote", OUT, flush=True)
+    with open(stamp, "w") as f:
+        f.write(digest)
     return OUT
 
 

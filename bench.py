@@ -47,14 +47,15 @@ def synth_conditioning(n, seed):
     return torch.nn.functional.layer_norm(torch.randn(n, 77, 1024, generator=g), (1024,))
 
 
-def cpu_baseline(ddim_steps_sample=4):
+def cpu_baseline(ddim_steps_sample=2):
     """Time the CPU oracle on this host: 1 latent with CFG, `ddim_steps_sample` of 100 DDIM steps (scaled),
     plus one full VAE decode and one full HiFi-GAN pass.  Returns audio-seconds per second for one clip."""
     from oracle import ddim as O_ddim
     from oracle import unet as O_unet
     from oracle import vae as O_vae
     from oracle import vocoder as O_voc
-    cores = os.cpu_count() or 1
+    # a bounded thread count: on a many-core host torch's intra-op pool oversubscribes badly past ~32 threads
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     usd = WT.make_unet_state_dict(C.UNET_T2A, seed=0)
     vsd = WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1, with_encoder=False)
@@ -65,6 +66,7 @@ def cpu_baseline(ddim_steps_sample=4):
     steps = O_ddim.ddim_timesteps(DDIM_STEPS)
     a, ap, sg, som = O_ddim.ddim_tables(ac, steps)
     with torch.no_grad():
+        O_unet.unet_forward(usd, C.UNET_T2A, torch.cat([x, x]), torch.tensor([991, 991]), torch.cat([uc, c]))  # warm-up
         t0 = time.perf_counter()
         for i in range(ddim_steps_sample):
             idx = DDIM_STEPS - 1 - i
