@@ -91,7 +91,7 @@ def load():
         "maa_ctx_synchronize": [vp],
         "maa_ctx_set_stream": [vp, vp],
         "maa_ctx_workspace_bytes": [vp, C.POINTER(C.c_size_t)],
-        "maa_prof_begin": [vp],
+        "maa_prof_begin": [vp, ci],
         "maa_prof_end": [vp, C.POINTER(maa_prof_row), ci, C.POINTER(ci)],
         "maa_unet_create": [vp, C.POINTER(maa_unet_config), C.POINTER(maa_tensor), ci, C.POINTER(vp)],
         "maa_unet_destroy": [vp],

@@ -45,15 +45,15 @@ class Context:
         L.check(self.lib.maa_ctx_workspace_bytes(self.h, C.byref(n)))
         return n.value
 
-    def prof_begin(self):
+    def prof_begin(self, detail=False):
         """Start per-kernel hipEvent timing of every launch on this context (eager launches only)."""
-        L.check(self.lib.maa_prof_begin(self.h))
+        L.check(self.lib.maa_prof_begin(self.h, int(detail)))
 
     def prof_end(self):
         """Stop timing; returns {kernel: dict(launches, ms, flops, bytes)}."""
-        rows = (L.maa_prof_row * 64)()
+        rows = (L.maa_prof_row * 512)()
         n = C.c_int()
-        L.check(self.lib.maa_prof_end(self.h, rows, 64, C.byref(n)))
+        L.check(self.lib.maa_prof_end(self.h, rows, 512, C.byref(n)))
         return {rows[i].name.decode(): dict(launches=int(rows[i].launches), ms=rows[i].ms, flops=rows[i].flops,
                                             bytes=rows[i].bytes) for i in range(n.value)}
 

@@ -16,7 +16,7 @@ OUT = os.path.join(HERE, "libaudiogpt_mi355x.so")
 SOURCES = ["igemm_f32.hip", "norm.hip", "misc.hip", "runtime.cpp", "blocks.cpp", "unet.cpp", "vae.cpp",
            "vocoder.cpp", "ddim.cpp", "api.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=off"]
+         "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _hipcc():

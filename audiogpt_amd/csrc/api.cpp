@@ -103,6 +103,12 @@ int maa_ctx_create(int device_id, void* hip_stream, maa_ctx** out) {
             c->c.stream = s;
             c->owns_stream = true;
         }
+        void* z = nullptr;
+        if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) {
+            delete c;
+            throw maa::Error("hipMalloc: zero page");
+        }
+        c->c.zeros = static_cast<float*>(z);
         *out = c;
     });
 }
@@ -112,6 +118,8 @@ int maa_ctx_destroy(maa_ctx* ctx) {
         (void)hipSetDevice(ctx->c.device);
         (void)hipStreamSynchronize(ctx->c.stream);
         if (ctx->owns_stream) (void)hipStreamDestroy(ctx->c.stream);
+        if (ctx->c.zeros) (void)hipFree(ctx->c.zeros);
+        delete ctx->c.prof;
         delete ctx;
     });
 }
@@ -137,10 +145,11 @@ int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out) {
     });
 }
 
-int maa_prof_begin(maa_ctx* ctx) {
+int maa_prof_begin(maa_ctx* ctx, int detail) {
     return guarded([&] {
         bind(ctx);
         if (!ctx->c.prof) ctx->c.prof = new maa::Profiler;
+        ctx->c.prof->detail = detail;
         ctx->c.prof->pending.clear();
         ctx->c.prof->next = 0;
     });

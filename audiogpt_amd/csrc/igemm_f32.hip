@@ -5,16 +5,17 @@
 //       reference: openaimodel.py:204,230,151-153,116-118,738  model.py:47-57,93-108
 //   linear / conv1x1 (taps = 1)         attention.py:161-168,40,60,233-248  openaimodel.py:241,304,312
 //   dilated conv1d k in {3,7,11}        NeuralSeq/modules/hifigan/hifigan.py:34-51 (sequence = image with H=1)
-//   ConvTranspose1d polyphase groups    hifigan.py:121-125 (see pack.cpp)
+//   ConvTranspose1d polyphase groups    hifigan.py:121-125 (see runtime.cpp)
 //   batched Q.K^T and P.V               attention.py:178-192, openaimodel.py:366-371, model.py:186-198
-// Fused: activation while staging A (leaky-ReLU / SiLU), bias, per-sample row add (time embedding,
-// openaimodel.py:264-273), residual add (:275), GEGLU (attention.py:42-44), tanh, MRF accumulate
-// (hifigan.py:158-164).
+// Fused: leaky-ReLU while staging A, bias, per-sample row add (time embedding, openaimodel.py:264-273),
+// residual add (:275), GEGLU (attention.py:42-44), tanh, MRF accumulate (hifigan.py:158-164).
 //
-// Layout: A rows are output positions (channels-last activations), K runs (ky, kx, ci); B is the
-// packed weight [K][N].  LDS tiles are k-major (A_lds[k][m], B_lds[k][n]) so that the f32 MFMA
-// operands (lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) are two conflict-free ds_read_b32 rows.
-// Global->register->LDS double buffering, one barrier per 16-deep K chunk.
+// Layout: A rows are output positions (channels-last activations), K runs (ky, kx, ci); B is the packed
+// weight [K][N].  LDS tiles are k-major (A_lds[k][m], B_lds[k][n]) so that the f32 MFMA operands
+// (lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) are two conflict-free ds_read_b32 rows.
+// Pipeline: global -> registers two K-chunks ahead (two register sets) -> LDS double buffer, one barrier per
+// 16-deep chunk.  The gather state (row pointers, validity) is recomputed only when the tap changes, so the
+// steady-state loop is loads + LDS traffic + MFMA with no integer division or 64-bit multiplies.
 #include "maa_internal.h"
 
 namespace maa {
@@ -26,14 +27,10 @@ namespace {
 constexpr int BK = 16;
 constexpr int NT = 256;
 
-__device__ __forceinline__ float apply_a_act(float v, int act, float slope) {
-    if (act == 1) return v > 0.f ? v : v * slope;
-    if (act == 2) return v / (1.f + expf(-v));
-    return v;
-}
-
-template <int BM, int BN, int WGM, int WGN, bool B_NK>
-__global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles, int fast_a, int Nb) {
+// GENERIC = true: per-element gather for convs whose channel count is not a multiple of 16 (first convs with
+// Cin = 1, 4, 9, 80) -- tiny share of the work, kept out of the fast kernel's loop.
+template <int BM, int BN, int WGM, int WGN, bool B_NK, bool GENERIC>
+__global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles, int Nb) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
     constexpr int LDA = BM + 2;
@@ -60,8 +57,13 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
     const int Ctot = p.C1 + p.C2;
     const int rpb = p.Hout * p.Wout;
     const int Hlim = p.Hin << p.up, Wlim = p.Win << p.up;
+    const int taps = p.KH * p.KW;
+    // Masked-out tile elements are loaded from a zero page instead of being branched around: every global load
+    // in the K loop is then unconditional, so the prefetches stay in flight behind counted s_waitcnt vmcnt(N).
+    const float4* g_zero4 = reinterpret_cast<const float4*>(p.zeros);
+    const float slope = p.a_act == 1 ? p.a_slope : 1.0f;     // leaky(x) = max(x, slope*x); slope 1 = identity
 
-    // ---- per-thread A row bookkeeping
+    // ---- per-thread A rows: output position -> (batch, top-left input coordinate)
     const int kq = tid & 3;
     int a_b[AL], a_iy0[AL], a_ix0[AL];
 #pragma unroll
@@ -82,49 +84,46 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
         }
     }
 
-    float4 ra[AL];
-    float4 rb[BL];
+    // ---- gather state of the tap being streamed
+    const float* a_p1[AL];
+    const float* a_p2[AL];
+    bool a_ok[AL];
+    int g_tap = 0, g_ci = 0;      // next chunk to load: tap index, first channel
+    auto set_tap = [&](int tap) {
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            int iy = a_iy0[j] + ky * p.dh, ix = a_ix0[j] + kx * p.dw;
+            const bool ok = a_b[j] >= 0 && iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim;
+            iy >>= p.up;
+            ix >>= p.up;
+            const long long off = ok ? ((long long)a_b[j] * p.Hin + iy) * p.Win + ix : 0;
+            a_ok[j] = ok;
+            a_p1[j] = a1 + off * p.lda1 + kq * 4;
+            a_p2[j] = a2 + off * p.lda2 + kq * 4 - p.C1;
+        }
+    };
 
-    auto load_a = [&](int k0, int tap, int ci0) {
-        if (fast_a) {
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-            const int kk = ci0 + kq * 4;
+    auto load_a = [&](float4 (&ra)[AL], int k0) {
+        if constexpr (!GENERIC) {
+            // chunk [g_ci, g_ci+16) of tap g_tap lies inside one source (C1 % 16 == 0 or single source)
+            const bool first = g_ci < p.C1;
+            const int cend = first ? p.C1 : Ctot;
+            const bool kin = g_ci + kq * 4 < cend;           // K tail (taps == 1, K % 16 != 0, K % 4 == 0)
 #pragma unroll
             for (int j = 0; j < AL; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                int iy = a_iy0[j] + ky * p.dh, ix = a_ix0[j] + kx * p.dw;
-                const bool ok = a_b[j] >= 0 && iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim;
-                if (ok) {
-                    iy >>= p.up;
-                    ix >>= p.up;
-                    const long long off = ((long long)a_b[j] * p.Hin + iy) * p.Win + ix;
-                    const float* src;
-                    int cend;
-                    if (kk < p.C1) {
-                        src = a1 + off * p.lda1 + kk;
-                        cend = p.C1;
-                    } else {
-                        src = a2 + off * p.lda2 + (kk - p.C1);
-                        cend = Ctot;
-                    }
-                    if (kk + 3 < cend) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        if (kk + 0 < cend) v.x = src[0];
-                        if (kk + 1 < cend) v.y = src[1];
-                        if (kk + 2 < cend) v.z = src[2];
-                    }
-                    if (p.a_act) {
-                        v.x = apply_a_act(v.x, p.a_act, p.a_slope);
-                        v.y = apply_a_act(v.y, p.a_act, p.a_slope);
-                        v.z = apply_a_act(v.z, p.a_act, p.a_slope);
-                        v.w = apply_a_act(v.w, p.a_act, p.a_slope);
-                    }
-                }
-                ra[j] = v;
+                const float4* src = reinterpret_cast<const float4*>((first ? a_p1[j] : a_p2[j]) + g_ci);
+                ra[j] = *((a_ok[j] && kin) ? src : g_zero4);
+                // (the activation is applied when the tile is written to LDS: the loaded value is not used
+                //  here, so the load stays in flight across the MFMA block)
+            }
+            g_ci += BK;
+            if (g_ci >= Ctot && g_tap + 1 < taps) {
+                g_ci = 0;
+                ++g_tap;
+                set_tap(g_tap);
             }
         } else {
-            // generic gather: any channel count / alignment (first convs with Cin = 1, 4, 9)
 #pragma unroll
             for (int j = 0; j < AL; ++j) {
                 float e[4] = {0.f, 0.f, 0.f, 0.f};
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
                             ix >>= p.up;
                             const long long off = ((long long)a_b[j] * p.Hin + iy) * p.Win + ix;
                             const float x = ci < p.C1 ? a1[off * p.lda1 + ci] : a2[off * p.lda2 + (ci - p.C1)];
-                            e[q] = apply_a_act(x, p.a_act, p.a_slope);
+                            e[q] = x;
                         }
                     }
                 }
@@ -149,48 +148,48 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
         }
     };
 
-    auto load_b = [&](int k0) {
+    // ---- B rows / columns of this thread (fixed), pointer advanced per chunk
+    const float* b_ptr[BL];
+    bool b_ok[BL];
+#pragma unroll
+    for (int j = 0; j < BL; ++j) {
         if (B_NK) {
-#pragma unroll
-            for (int j = 0; j < BL; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int nrow = (tid >> 2) + 64 * j;
-                const int n = n0 + nrow, k = k0 + kq * 4;
-                if (nrow < BN && n < p.N && k < p.K) {
-                    const float* src = bp + (long long)n * p.ldb + k;
-                    if (k + 3 < p.K) {
-                        v = *reinterpret_cast<const float4*>(src);
-                    } else {
-                        v.x = src[0];
-                        if (k + 1 < p.K) v.y = src[1];
-                        if (k + 2 < p.K) v.z = src[2];
-                    }
-                }
-                rb[j] = v;
-            }
+            const int nrow = (tid >> 2) + 64 * j;
+            const int n = n0 + nrow;
+            b_ok[j] = nrow < BN && n < p.N;
+            b_ptr[j] = bp + (long long)(b_ok[j] ? n : 0) * p.ldb + kq * 4;
         } else {
+            const int idx = tid + NT * j;
+            const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
+            const int n = n0 + nq * 4;
+            b_ok[j] = kr < BK && n < Nb;
+            b_ptr[j] = bp + (long long)kr * p.ldb + (b_ok[j] ? n : 0);
+        }
+    }
+    auto load_b = [&](float4 (&rb)[BL], int k0) {
 #pragma unroll
-            for (int j = 0; j < BL; ++j) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int idx = tid + NT * j;
-                const int kr = idx / (BN / 4), nq = idx - kr * (BN / 4);
-                const int k = k0 + kr, n = n0 + nq * 4;
-                if (kr < BK && k < p.K && n < Nb) v = *reinterpret_cast<const float4*>(bp + (long long)k * p.ldb + n);
-                rb[j] = v;
+        for (int j = 0; j < BL; ++j) {
+            if (B_NK) {
+                const float4* src = reinterpret_cast<const float4*>(b_ptr[j] + k0);
+                rb[j] = *((b_ok[j] && k0 + kq * 4 < p.K) ? src : g_zero4);
+            } else {
+                const int kr = (tid + NT * j) / (BN / 4);
+                const float4* src = reinterpret_cast<const float4*>(b_ptr[j] + (long long)k0 * p.ldb);
+                rb[j] = *((b_ok[j] && k0 + kr < p.K) ? src : g_zero4);
             }
         }
     };
 
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](const float4 (&ra)[AL], const float4 (&rb)[BL], int buf) {
         float* A = As + buf * BK * LDA;
         float* B = Bs + buf * BK * LDB;
 #pragma unroll
         for (int j = 0; j < AL; ++j) {
             const int row = (tid >> 2) + 64 * j;
-            A[(kq * 4 + 0) * LDA + row] = ra[j].x;
-            A[(kq * 4 + 1) * LDA + row] = ra[j].y;
-            A[(kq * 4 + 2) * LDA + row] = ra[j].z;
-            A[(kq * 4 + 3) * LDA + row] = ra[j].w;
+            A[(kq * 4 + 0) * LDA + row] = fmaxf(ra[j].x, ra[j].x * slope);
+            A[(kq * 4 + 1) * LDA + row] = fmaxf(ra[j].y, ra[j].y * slope);
+            A[(kq * 4 + 2) * LDA + row] = fmaxf(ra[j].z, ra[j].z * slope);
+            A[(kq * 4 + 3) * LDA + row] = fmaxf(ra[j].w, ra[j].w * slope);
         }
         if (B_NK) {
 #pragma unroll
@@ -227,24 +226,7 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
     const int lrow = lane & 31, lk = lane >> 5;
     const int a_base = wm * WTM + lrow, b_base = wn * WTN + lrow;
 
-    const int nchunks = (p.K + BK - 1) / BK;
-    int tap = 0, ci0 = 0;
-    load_a(0, tap, ci0);
-    load_b(0);
-    store_tiles(0);
-    __syncthreads();
-
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) {
-            ci0 += BK;
-            if (ci0 >= Ctot && p.KH * p.KW > 1) {
-                ci0 = 0;
-                ++tap;
-            }
-            load_a((c + 1) * BK, tap, ci0);
-            load_b((c + 1) * BK);
-        }
+    auto compute = [&](int buf) {
         const float* A = As + buf * BK * LDA;
         const float* B = Bs + buf * BK * LDB;
 #pragma unroll
@@ -260,7 +242,32 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < nchunks) store_tiles(buf ^ 1);
+    };
+
+    // ---- main loop: register sets R0/R1 hold chunks c+1 / c+2 while chunk c is computed from LDS
+    const int nchunks = (p.K + BK - 1) / BK;
+    float4 ra0[AL], rb0[BL], ra1[AL], rb1[BL];
+    if constexpr (!GENERIC) set_tap(0);
+    load_a(ra0, 0);
+    load_b(rb0, 0);
+    load_a(ra1, BK);
+    load_b(rb1, BK);
+    store_tiles(ra0, rb0, 0);
+    __syncthreads();
+    // The loop body is branch-free: chunks past K load zeros (and add nothing), so an odd chunk count costs
+    // one empty MFMA block instead of a data-dependent exit in the middle of the pipeline.
+    for (int c = 0; c < nchunks; c += 2) {
+        // even step: chunk c in LDS buf 0, chunk c+1 in R1, R0 free -> prefetch chunk c+2
+        load_a(ra0, (c + 2) * BK);
+        load_b(rb0, (c + 2) * BK);
+        compute(0);
+        store_tiles(ra1, rb1, 1);
+        __syncthreads();
+        // odd step: chunk c+1 in LDS buf 1, chunk c+2 in R0, R1 free -> prefetch chunk c+3
+        load_a(ra1, (c + 3) * BK);
+        load_b(rb1, (c + 3) * BK);
+        compute(1);
+        store_tiles(ra0, rb0, 0);
         __syncthreads();
     }
 
@@ -320,15 +327,17 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
 }
 
 template <int BM, int BN, int WGM, int WGN>
-void launch_cfg(const Ctx& ctx, const IGemm& p, int fast_a, int Nb) {
+void launch_cfg(const Ctx& ctx, const IGemm& p, bool generic, int Nb) {
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N * (p.geglu ? 2 : 1) + BN - 1) / BN;
     dim3 grid((unsigned)((long long)mtiles * ntiles), (unsigned)p.Z);
-    if (p.b_nk)
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, true>), grid, dim3(NT), 0, ctx.stream, p, ntiles,
-                           fast_a, Nb);
-    else
-        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, false>), grid, dim3(NT), 0, ctx.stream, p, ntiles,
-                           fast_a, Nb);
+    if (generic) {
+        MAA_CHECK(!p.b_nk, "generic gather with a transposed B operand");
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, false, true>), grid, dim3(NT), 0, ctx.stream, p, ntiles, Nb);
+    } else if (p.b_nk) {
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, true, false>), grid, dim3(NT), 0, ctx.stream, p, ntiles, Nb);
+    } else {
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, false, false>), grid, dim3(NT), 0, ctx.stream, p, ntiles, Nb);
+    }
 }
 
 inline double tile_cost(long long M, long long N, int Z, int BM, int BN, double eff) {
@@ -339,26 +348,35 @@ inline double tile_cost(long long M, long long N, int Z, int BM, int BN, double 
 
 }  // namespace
 
-void launch_igemm(const Ctx& ctx, const IGemm& p) {
+void launch_igemm(const Ctx& ctx, const IGemm& p_in) {
     if (ctx.ws.dry) return;
+    IGemm p = p_in;
+    p.zeros = ctx.zeros;
+    MAA_CHECK(p.zeros != nullptr, "context has no zero page");
     MAA_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty igemm");
-    MAA_CHECK(p.K == p.KH * p.KW * (p.C1 + p.C2), "igemm K mismatch");
     const int taps = p.KH * p.KW, Ctot = p.C1 + p.C2;
+    MAA_CHECK(p.K <= taps * Ctot && p.K > (taps - 1) * Ctot, "igemm K mismatch");
+    MAA_CHECK(p.a_act == 0 || p.a_act == 1, "igemm A activation");
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    int fast_a = (taps == 1 || (Ctot % BK == 0 && p.C1 % BK == 0)) && p.lda1 % 4 == 0 && al16(p.a1) &&
-                 p.a_so % 4 == 0 && p.a_si % 4 == 0;
-    if (p.C2 > 0) fast_a = fast_a && p.C1 % 4 == 0 && p.lda2 % 4 == 0 && al16(p.a2);
+    // fast gather: 16-channel chunks never straddle a tap or a source, float4 loads are aligned
+    // (single source, K % 4 != 0: the last float4 over-reads up to 3 floats of the same row, which must exist
+    //  and be finite -- e.g. the zeroed padding columns of the attention scores; they meet zero rows of B)
+    bool fast = (taps == 1 ? (p.C2 == 0 ? (Ctot % 4 == 0 || p.lda1 >= (Ctot + 3) / 4 * 4)
+                                        : (p.C1 % BK == 0 && Ctot % 4 == 0))
+                           : (Ctot % BK == 0 && p.C1 % BK == 0)) &&
+                p.lda1 % 4 == 0 && al16(p.a1) && p.a_so % 4 == 0 && p.a_si % 4 == 0;
+    if (p.C2 > 0) fast = fast && p.lda2 % 4 == 0 && al16(p.a2);
     if (p.Z > 1) MAA_CHECK(p.C2 == 0, "batched igemm takes one A source");
+    MAA_CHECK(fast || p.K == taps * Ctot, "padded K needs the aligned gather");
     // columns that may be read from B: packed weights are zero-padded to a multiple of 32
     const int ncols = p.N * (p.geglu ? 2 : 1);
     int Nb = ncols;
+    MAA_CHECK(p.ldb % 4 == 0 && al16(p.b) && p.b_so % 4 == 0 && p.b_si % 4 == 0, "B operand alignment");
     if (!p.b_nk) {
-        MAA_CHECK(p.ldb % 4 == 0 && al16(p.b) && p.b_so % 4 == 0 && p.b_si % 4 == 0, "B [K][N] alignment");
         Nb = (ncols + 3) / 4 * 4;
-        MAA_CHECK(Nb <= p.ldb || p.Z == 1, "B column padding");
         if (Nb > p.ldb) Nb = p.ldb / 4 * 4;
     } else {
-        MAA_CHECK(p.ldb % 4 == 0 && al16(p.b) && p.b_so % 4 == 0 && p.b_si % 4 == 0, "B [N][K] alignment");
+        MAA_CHECK(p.K % 4 == 0, "B [N][K] needs K % 4 == 0");
     }
     // algorithmic work of this launch: 2*M*N*K per batch entry (GEGLU computes 2N columns)
     const double flops = 2.0 * p.M * (double)ncols * p.K * p.Z;
@@ -376,12 +394,19 @@ void launch_igemm(const Ctx& ctx, const IGemm& p) {
         cfg = (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
     }
     static const char* kNames[4] = {"igemm_f32<128x128>", "igemm_f32<128x64>", "igemm_f32<64x64>", "igemm_f32<256x32>"};
-    ProfScope prof(ctx, kNames[cfg], flops, bytes);
+    char shape_name[48];
+    const char* pname = kNames[cfg];
+    if (ctx.prof && ctx.prof->detail) {
+        std::snprintf(shape_name, sizeof(shape_name), "ig%d M%d N%d K%d t%d Z%d%s", cfg, p.M, ncols, p.K, taps, p.Z,
+                      p.b_nk ? "T" : "");
+        pname = shape_name;
+    }
+    ProfScope prof(ctx, pname, flops, bytes);
     switch (cfg) {
-        case 0: launch_cfg<128, 128, 2, 2>(ctx, p, fast_a, Nb); break;
-        case 1: launch_cfg<128, 64, 2, 2>(ctx, p, fast_a, Nb); break;
-        case 2: launch_cfg<64, 64, 2, 2>(ctx, p, fast_a, Nb); break;
-        default: launch_cfg<256, 32, 4, 1>(ctx, p, fast_a, Nb); break;
+        case 0: launch_cfg<128, 128, 2, 2>(ctx, p, !fast, Nb); break;
+        case 1: launch_cfg<128, 64, 2, 2>(ctx, p, !fast, Nb); break;
+        case 2: launch_cfg<64, 64, 2, 2>(ctx, p, !fast, Nb); break;
+        default: launch_cfg<256, 32, 4, 1>(ctx, p, !fast, Nb); break;
     }
     MAA_HIP(hipGetLastError());
 }

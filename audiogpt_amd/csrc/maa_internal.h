@@ -70,6 +70,7 @@ public:
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
     size_t next = 0;
+    int detail = 0;      // 1: igemm rows are keyed by problem shape
     std::vector<ProfRow> collect(hipStream_t stream);   // synchronises, aggregates by name, clears
 };
 struct Ctx;
@@ -82,6 +83,7 @@ struct ProfScope {     // records an event pair around the launches issued durin
 
 struct Ctx {
     Profiler* prof = nullptr;
+    float* zeros = nullptr;   // 256 B zero page (device), source of masked tile loads
     int device = 0;
     hipStream_t stream = nullptr;
     Arena ws;
@@ -124,6 +126,7 @@ struct IGemm {
     int accumulate = 0;              // c += value instead of c = value
     float* c = nullptr;
     int ldc = 0;
+    const float* zeros = nullptr;    // >= 16 B of zeros in device memory (filled in by launch_igemm)
 };
 void launch_igemm(const Ctx& ctx, const IGemm& p);
 

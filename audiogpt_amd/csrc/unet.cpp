@@ -416,12 +416,14 @@ struct UNet::Impl {
         float* e1 = ctx.ws.alloc_f((size_t)B * emb_dim);
         linear_into(ctx, te, mc, B, mc, te0, nullptr, 0, e1, emb_dim);
         float* emb = ctx.ws.alloc_f((size_t)B * emb_dim);
-        // second linear reads SiLU(e1) through the A-staging activation; I2A adds context.squeeze(1) as residual
-        linear_into(ctx, e1, emb_dim, B, emb_dim, te2, cfg.add_context_to_emb ? context : nullptr, emb_dim, emb, emb_dim,
-                    0, /*a_act=*/2);
+        launch_silu(ctx, e1, (long long)B * emb_dim, e1);
+        // I2A adds context.squeeze(1) to the embedding (custom_openaimodel.py:352-354): a residual of the GEMM
+        linear_into(ctx, e1, emb_dim, B, emb_dim, te2, cfg.add_context_to_emb ? context : nullptr, emb_dim, emb, emb_dim);
         // all ResBlock emb_layers at once: Linear(SiLU(emb)) (openaimodel.py:218-224, 264)
+        float* semb = ctx.ws.alloc_f((size_t)B * emb_dim);
+        launch_silu(ctx, emb, (long long)B * emb_dim, semb);
         float* emb_out = ctx.ws.alloc_f((size_t)B * emb_all.Npad);
-        linear_into(ctx, emb, emb_dim, B, emb_dim, emb_all, nullptr, 0, emb_out, emb_all.Npad, 0, /*a_act=*/2);
+        linear_into(ctx, semb, emb_dim, B, emb_dim, emb_all, nullptr, 0, emb_out, emb_all.Npad);
 
         T4 h = alloc_t(ctx, B, H, W, cfg.in_channels);
         launch_nchw_to_nhwc(ctx, x_nchw, B, cfg.in_channels, H * W, h.p);

@@ -65,7 +65,7 @@ typedef struct maa_prof_row {
     double flops;    /* sum of algorithmic flops (2*M*N*K for the contractions) */
     double bytes;    /* sum of algorithmic bytes (compulsory reads + writes) */
 } maa_prof_row;
-int maa_prof_begin(maa_ctx* ctx);
+int maa_prof_begin(maa_ctx* ctx, int detail);   /* detail 1: contraction rows are keyed by problem shape */
 int maa_prof_end(maa_ctx* ctx, maa_prof_row* rows, int max_rows, int* n_rows);
 
 /* one named fp32 host tensor of a reference state_dict */
