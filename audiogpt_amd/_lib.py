@@ -61,7 +61,7 @@ class maa_vocoder_config(C.Structure):
 
 EXPORTS = [
     "maa_last_error", "maa_version", "maa_ctx_create", "maa_ctx_destroy", "maa_ctx_synchronize",
-    "maa_ctx_set_stream", "maa_ctx_workspace_bytes", "maa_prof_begin", "maa_prof_end", "maa_unet_create", "maa_unet_destroy",
+    "maa_ctx_set_stream", "maa_ctx_set_precision", "maa_ctx_workspace_bytes", "maa_prof_begin", "maa_prof_end", "maa_unet_create", "maa_unet_destroy",
     "maa_unet_set_context", "maa_unet_forward", "maa_ddim_update", "maa_ddim_sample", "maa_vae_create",
     "maa_vae_destroy", "maa_vae_decode", "maa_vae_encode_moments", "maa_vocoder_create", "maa_vocoder_destroy",
     "maa_vocoder_forward", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
@@ -91,6 +91,7 @@ def load():
         "maa_ctx_synchronize": [vp],
         "maa_ctx_set_stream": [vp, vp],
         "maa_ctx_workspace_bytes": [vp, C.POINTER(C.c_size_t)],
+        "maa_ctx_set_precision": [vp, ci],
         "maa_prof_begin": [vp, ci],
         "maa_prof_end": [vp, C.POINTER(maa_prof_row), ci, C.POINTER(ci)],
         "maa_unet_create": [vp, C.POINTER(maa_unet_config), C.POINTER(maa_tensor), ci, C.POINTER(vp)],

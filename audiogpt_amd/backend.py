@@ -20,7 +20,9 @@ class Context:
     """One (device, stream) execution context.  Calls are serialised with a lock, like the reference's
     non re-entrant sampler (ddim.py:27-56)."""
 
-    def __init__(self, device="cuda:0", stream=None):
+    PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+    def __init__(self, device="cuda:0", stream=None, precision="f32"):
         self.lib = L.load()
         if not torch.cuda.is_available():
             raise L.MaaError("no MI355X visible: the HIP backend has no CPU fallback")
@@ -36,6 +38,13 @@ class Context:
         L.check(self.lib.maa_ctx_create(idx, sp, C.byref(h)))
         self.h = h
         self.lock = threading.RLock()
+        self.precision = "f32"
+        self.set_precision(precision)
+
+    def set_precision(self, precision):
+        """Arithmetic of the contractions for models created from now on (and for the op_* calls)."""
+        L.check(self.lib.maa_ctx_set_precision(self.h, self.PRECISIONS[precision]))
+        self.precision = precision
 
     def synchronize(self):
         L.check(self.lib.maa_ctx_synchronize(self.h))

@@ -145,6 +145,14 @@ int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out) {
     });
 }
 
+int maa_ctx_set_precision(maa_ctx* ctx, int mode) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(mode >= 0 && mode <= 2, "precision mode must be 0 (fp32), 1 (bf16x3) or 2 (bf16)");
+        ctx->c.dtype = mode;
+    });
+}
+
 int maa_prof_begin(maa_ctx* ctx, int detail) {
     return guarded([&] {
         bind(ctx);
@@ -186,7 +194,7 @@ int maa_unet_create(maa_ctx* ctx, const maa_unet_config* cfg, const maa_tensor* 
                   "unsupported UNet config");
         auto sd = to_state_dict(tensors, n_tensors);
         auto* u = new maa_unet;
-        u->m.reset(new maa::UNet(*cfg, sd));
+        u->m.reset(new maa::UNet(*cfg, sd, ctx->c.dtype));
         *out = u;
     });
 }
@@ -232,7 +240,7 @@ int maa_vae_create(maa_ctx* ctx, const maa_vae_config* cfg, const maa_tensor* te
         MAA_CHECK(cfg && out && cfg->n_ch_mult > 0 && cfg->n_ch_mult <= 8, "bad VAE config");
         auto sd = to_state_dict(tensors, n_tensors);
         auto* v = new maa_vae;
-        v->m.reset(new maa::VAE(*cfg, sd));
+        v->m.reset(new maa::VAE(*cfg, sd, ctx->c.dtype));
         *out = v;
     });
 }
@@ -264,7 +272,7 @@ int maa_vocoder_create(maa_ctx* ctx, const maa_vocoder_config* cfg, const maa_te
                   "bad vocoder config");
         auto sd = to_state_dict(tensors, n_tensors);
         auto* v = new maa_vocoder;
-        v->m.reset(new maa::Vocoder(*cfg, sd));
+        v->m.reset(new maa::Vocoder(*cfg, sd, ctx->c.dtype));
         *out = v;
     });
 }
@@ -288,7 +296,7 @@ int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w
         OneShot s;
         s.add("w", h_w, {N, K});
         if (h_bias) s.add("b", h_bias, {N});
-        maa::WeightStore ws;
+        maa::WeightStore ws(ctx->c.dtype != 0);
         maa::Ctx& c = ctx->c;
         if (geglu) {
             MAA_CHECK(h_bias, "geglu needs a bias");
@@ -311,7 +319,7 @@ int maa_op_conv(maa_ctx* ctx, const float* d_x, int B, int Cin, int H, int W, co
         OneShot s;
         s.add("w", h_w, {Cout, Cin, KH, KW});
         if (h_bias) s.add("b", h_bias, {Cout});
-        maa::WeightStore ws;
+        maa::WeightStore ws(ctx->c.dtype != 0);
         maa::Ctx& c = ctx->c;
         maa::PackedW pw = ws.pack_conv(s.sd, "w", h_bias ? "b" : "", KH, KW);
         maa::run_sized(c, [&] {
@@ -341,7 +349,7 @@ int maa_op_groupnorm(maa_ctx* ctx, const float* d_x, int B, int C, int HW, const
     return guarded([&] {
         bind(ctx);
         MAA_CHECK(d_x && h_gamma && h_beta && d_y, "bad op_groupnorm arguments");
-        maa::WeightStore ws;
+        maa::WeightStore ws(ctx->c.dtype != 0);
         maa::Ctx& c = ctx->c;
         float* g = ws.upload(std::vector<float>(h_gamma, h_gamma + C));
         float* b = ws.upload(std::vector<float>(h_beta, h_beta + C));
@@ -360,7 +368,7 @@ int maa_op_layernorm(maa_ctx* ctx, const float* d_x, int rows, int C, const floa
     return guarded([&] {
         bind(ctx);
         MAA_CHECK(d_x && h_gamma && h_beta && d_y, "bad op_layernorm arguments");
-        maa::WeightStore ws;
+        maa::WeightStore ws(ctx->c.dtype != 0);
         maa::Ctx& c = ctx->c;
         float* g = ws.upload(std::vector<float>(h_gamma, h_gamma + C));
         float* b = ws.upload(std::vector<float>(h_beta, h_beta + C));
@@ -391,7 +399,7 @@ int maa_op_conv_transpose1d(maa_ctx* ctx, const float* d_x, int B, int Cin, int 
         OneShot s;
         s.add("w", h_w, {Cin, Cout, k});
         s.add("b", h_bias, {Cout});
-        maa::WeightStore ws;
+        maa::WeightStore ws(ctx->c.dtype != 0);
         maa::Ctx& c = ctx->c;
         const int pad = (k - stride) / 2, U = k / stride;
         maa::run_sized(c, [&] {
@@ -417,7 +425,8 @@ int maa_op_conv_transpose1d(maa_ctx* ctx, const float* d_x, int B, int Cin, int 
                     p.a_slope = leaky_slope;
                 }
                 p.b = pw.w;
-                p.ldb = pw.Npad;
+                p.ldb = pw.ld;
+                p.b_nk = pw.nk;
                 p.M = B * L;
                 p.K = U * Cin;
                 p.N = r_count * Cout;
@@ -437,7 +446,7 @@ int maa_op_snake_aa(maa_ctx* ctx, const float* d_x, int B, int C, int L, const f
     return guarded([&] {
         bind(ctx);
         MAA_CHECK(d_x && h_alpha && h_beta && d_y, "bad op_snake_aa arguments");
-        maa::WeightStore ws;
+        maa::WeightStore ws(ctx->c.dtype != 0);
         maa::Ctx& c = ctx->c;
         std::vector<float> ha(C), hib(C);
         for (int i = 0; i < C; ++i) {

@@ -27,7 +27,8 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
     p.a_act = o.a_act;
     p.a_slope = o.a_slope;
     p.b = w.w;
-    p.ldb = w.Npad;
+    p.ldb = w.ld;
+    p.b_nk = w.nk;
     p.M = out.B * out.H * out.W;
     p.K = o.KH * o.KW * (p.C1 + p.C2);
     MAA_CHECK(p.K == w.K, "conv weight K mismatch");
@@ -60,7 +61,8 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
     MAA_CHECK(K == w.K, "linear weight K mismatch");
     p.N = w.N;
     p.b = w.w;
-    p.ldb = w.Npad;
+    p.ldb = w.ld;
+    p.b_nk = w.nk;
     p.bias = w.bias;
     p.res = res;
     p.ldr = ldr;

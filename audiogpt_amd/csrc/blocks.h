@@ -49,6 +49,14 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
 void attention_into(Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk, const float* v,
                     int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha, float* out, int ldo);
 
+// Run a model under its own precision mode (the mode its weights were packed for)
+struct PrecisionGuard {
+    Ctx& ctx;
+    int saved;
+    PrecisionGuard(Ctx& c, int mode) : ctx(c), saved(c.dtype) { c.dtype = mode; }
+    ~PrecisionGuard() { ctx.dtype = saved; }
+};
+
 // Size the workspace with a dry run of `f` (allocations counted, launches skipped), grow the slab if needed
 // (never during graph capture: sizes are fixed per shape), then run `f` for real.
 template <class F>

@@ -1,0 +1,330 @@
+// Implicit-GEMM engine on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, gfx950), fp32 in / fp32 out.
+//
+// Same problem description (IGemm), gather and epilogue as igemm_f32.hip; what changes is how the fp32 operands
+// reach the MFMA:
+//   TERMS = 3  "bf16x3": every fp32 operand is split on the fly into hi = bf16(x) and lo = bf16(x - hi) while its
+//              tile is written to LDS, and the product is formed as lo*hi + hi*lo + hi*hi with fp32 accumulation.
+//              hi+lo carries 16 mantissa bits, so a product is good to ~2^-16 instead of bf16's 2^-8, at 3 MFMAs
+//              per 16-deep k-step: 16/3 = 5.3x the fp32 MFMA rate (gfx950 has no TF32/xf32, and its fp32 MFMA runs
+//              at 1/16 of the bf16 rate, so this is the fast path that still meets the fp32 parity gates).
+//   TERMS = 1  plain bf16 operands (throughput mode; error reported, not gated at 1e-4).
+// LDS tiles are row-major with k contiguous ([m][32 k] bf16, row pitch 40 = 80 B, which makes the 16-lane groups of
+// ds_read_b128 hit 16 distinct 16-byte slots): a lane's MFMA operand (8 consecutive k of one row) is one
+// ds_read_b128.  B must be given k-contiguous ([N][K]: packed weights in this mode, and K of Q.K^T).
+#include "igemm_epilogue.h"
+
+namespace maa {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = 40;      // bf16 elements per LDS row (32 + 8 pad)
+constexpr int NT = 256;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    f32x2 f = {a, b};
+    bf16x2 h = __builtin_convertvector(f, bf16x2);      // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, h);
+}
+// (a, b) -> packed hi pair and packed lo pair
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pk_bf16(a, b);
+    const float fa = __builtin_bit_cast(float, hi << 16);
+    const float fb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    lo = pk_bf16(a - fa, b - fb);
+}
+
+template <int BM, int BN, int WGM, int WGN, int TERMS>
+__global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntiles, int Nb) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int MI = WTM / 32, NI = WTN / 32;
+    constexpr int AL = BM / 32, BL = BN / 32;          // float4 per thread per chunk
+    constexpr int PLANES = TERMS == 1 ? 1 : 2;
+    constexpr int ROWS = BM + BN;
+    constexpr int PLANE_ELEMS = ROWS * LDK;            // bf16 elements of one plane of one buffer
+    static_assert(WGM * WGN == 4 && BM % 32 == 0 && BN % 32 == 0, "tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // [buf][plane][row][LDK]
+
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    const int nt = bid % ntiles, mt = bid / ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int z = blockIdx.y;
+    const int zo = z / p.zin, zi = z - zo * p.zin;
+    const float* a1 = p.a1 + zo * p.a_so + zi * p.a_si;
+    const float* a2 = p.a2;
+    const float* bp = p.b + zo * p.b_so + zi * p.b_si;
+    const long long coff = zo * p.c_so + zi * p.c_si;
+
+    const int Ctot = p.C1 + p.C2;
+    const int rpb = p.Hout * p.Wout;
+    const int Hlim = p.Hin << p.up, Wlim = p.Win << p.up;
+    const int taps = p.KH * p.KW;
+    const float4* g_zero4 = reinterpret_cast<const float4*>(p.zeros);
+    const float slope = p.a_act == 1 ? p.a_slope : 1.0f;
+
+    // ---- per-thread A rows
+    const int kq = tid & 7, trow = tid >> 3;
+    int a_b[AL], a_iy0[AL], a_ix0[AL];
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+        const int m = m0 + trow + 32 * j;
+        if (m < p.M) {
+            const int b = m / rpb;
+            const int rem = m - b * rpb;
+            const int oy = rem / p.Wout;
+            const int ox = rem - oy * p.Wout;
+            a_b[j] = b;
+            a_iy0[j] = oy * p.sh - p.ph;
+            a_ix0[j] = ox * p.sw - p.pw;
+        } else {
+            a_b[j] = -1;
+            a_iy0[j] = 0;
+            a_ix0[j] = 0;
+        }
+    }
+    const float* a_p1[AL];
+    const float* a_p2[AL];
+    bool a_ok[AL];
+    int g_tap = 0, g_ci = 0;
+    auto set_tap = [&](int tap) {
+        const int ky = tap / p.KW, kx = tap - ky * p.KW;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            int iy = a_iy0[j] + ky * p.dh, ix = a_ix0[j] + kx * p.dw;
+            const bool ok = a_b[j] >= 0 && iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim;
+            iy >>= p.up;
+            ix >>= p.up;
+            const long long off = ok ? ((long long)a_b[j] * p.Hin + iy) * p.Win + ix : 0;
+            a_ok[j] = ok;
+            a_p1[j] = a1 + off * p.lda1 + kq * 4;
+            a_p2[j] = a2 + off * p.lda2 + kq * 4 - p.C1;
+        }
+    };
+    auto load_a = [&](float4 (&ra)[AL]) {
+        const bool first = g_ci < p.C1;
+        const int cend = first ? p.C1 : Ctot;
+        const bool kin = g_ci + kq * 4 < cend;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            const float4* src = reinterpret_cast<const float4*>((first ? a_p1[j] : a_p2[j]) + g_ci);
+            ra[j] = *((a_ok[j] && kin) ? src : g_zero4);
+        }
+        g_ci += BK;
+        if (g_ci >= Ctot && g_tap + 1 < taps) {
+            g_ci = 0;
+            ++g_tap;
+            set_tap(g_tap);
+        }
+    };
+
+    // ---- B rows ([N][K], k contiguous)
+    const float* b_ptr[BL];
+    bool b_ok[BL];
+#pragma unroll
+    for (int j = 0; j < BL; ++j) {
+        const int n = n0 + trow + 32 * j;
+        b_ok[j] = n < Nb;
+        b_ptr[j] = bp + (long long)(b_ok[j] ? n : 0) * p.ldb + kq * 4;
+    }
+    auto load_b = [&](float4 (&rb)[BL], int k0) {
+#pragma unroll
+        for (int j = 0; j < BL; ++j) {
+            const float4* src = reinterpret_cast<const float4*>(b_ptr[j] + k0);
+            rb[j] = *((b_ok[j] && k0 + kq * 4 < p.K) ? src : g_zero4);
+        }
+    };
+
+    auto store_tiles = [&](const float4 (&ra)[AL], const float4 (&rb)[BL], int buf) {
+        unsigned short* base = smem + buf * PLANES * PLANE_ELEMS;
+#pragma unroll
+        for (int j = 0; j < AL; ++j) {
+            float4 v = ra[j];
+            v.x = fmaxf(v.x, v.x * slope);
+            v.y = fmaxf(v.y, v.y * slope);
+            v.z = fmaxf(v.z, v.z * slope);
+            v.w = fmaxf(v.w, v.w * slope);
+            const int e = (trow + 32 * j) * LDK + kq * 4;
+            uint2 hi, lo;
+            if constexpr (TERMS == 1) {
+                hi.x = pk_bf16(v.x, v.y);
+                hi.y = pk_bf16(v.z, v.w);
+                *reinterpret_cast<uint2*>(base + e) = hi;
+            } else {
+                split2(v.x, v.y, hi.x, lo.x);
+                split2(v.z, v.w, hi.y, lo.y);
+                *reinterpret_cast<uint2*>(base + e) = hi;
+                *reinterpret_cast<uint2*>(base + PLANE_ELEMS + e) = lo;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BL; ++j) {
+            const float4 v = rb[j];
+            const int e = (BM + trow + 32 * j) * LDK + kq * 4;
+            uint2 hi, lo;
+            if constexpr (TERMS == 1) {
+                hi.x = pk_bf16(v.x, v.y);
+                hi.y = pk_bf16(v.z, v.w);
+                *reinterpret_cast<uint2*>(base + e) = hi;
+            } else {
+                split2(v.x, v.y, hi.x, lo.x);
+                split2(v.z, v.w, hi.y, lo.y);
+                *reinterpret_cast<uint2*>(base + e) = hi;
+                *reinterpret_cast<uint2*>(base + PLANE_ELEMS + e) = lo;
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WGN, wn = wid - wm * WGN;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int a_off = (wm * WTM + lrow) * LDK + lk * 8;
+    const int b_off = (BM + wn * WTN + lrow) * LDK + lk * 8;
+
+    auto compute = [&](int buf) {
+        const unsigned short* base = smem + buf * PLANES * PLANE_ELEMS;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 ah[MI], bh[NI], al[MI], bl[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 32 * LDK + ks * 16);
+                if constexpr (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(base + PLANE_ELEMS + a_off + i * 32 * LDK + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 32 * LDK + ks * 16);
+                if constexpr (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(base + PLANE_ELEMS + b_off + j * 32 * LDK + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    if constexpr (TERMS == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- main loop (same two-ahead register pipeline as the fp32 kernel)
+    const int nchunks = (p.K + BK - 1) / BK;
+    float4 ra0[AL], rb0[BL], ra1[AL], rb1[BL];
+    set_tap(0);
+    load_a(ra0);
+    load_b(rb0, 0);
+    load_a(ra1);
+    load_b(rb1, BK);
+    store_tiles(ra0, rb0, 0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += 2) {
+        load_a(ra0);
+        load_b(rb0, (c + 2) * BK);
+        compute(0);
+        store_tiles(ra1, rb1, 1);
+        __syncthreads();
+        load_a(ra1);
+        load_b(rb1, (c + 3) * BK);
+        compute(1);
+        store_tiles(ra0, rb0, 0);
+        __syncthreads();
+    }
+
+    igemm_epilogue<MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lrow, lk, coff, Nb, rpb);
+}
+
+template <int BM, int BN, int WGM, int WGN, int TERMS>
+void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
+    const int ncols = p.N * (p.geglu ? 2 : 1);
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = (ncols + BN - 1) / BN;
+    dim3 grid((unsigned)((long long)mtiles * ntiles), (unsigned)p.Z);
+    constexpr int planes = TERMS == 1 ? 1 : 2;
+    constexpr size_t lds = (size_t)2 * planes * (BM + BN) * LDK * sizeof(unsigned short);
+    auto kern = igemm_bf16_kernel<BM, BN, WGM, WGN, TERMS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, p, ntiles, Nb);
+}
+
+template <int TERMS>
+void launch_terms(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
+    switch (cfg) {
+        case 0: launch_one<128, 128, 2, 2, TERMS>(ctx, p, Nb); break;
+        case 1: launch_one<128, 64, 2, 2, TERMS>(ctx, p, Nb); break;
+        case 2: launch_one<64, 64, 2, 2, TERMS>(ctx, p, Nb); break;
+        default: launch_one<256, 32, 4, 1, TERMS>(ctx, p, Nb); break;
+    }
+}
+
+inline double tile_cost(long long M, long long N, int Z, int BM, int BN, double eff) {
+    const long long blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * Z;
+    const long long rounds = (blocks + 255) / 256;
+    return (double)rounds * BM * BN / eff;
+}
+
+}  // namespace
+
+// Returns false when the problem cannot take this path (B not k-contiguous, channel counts that are not a
+// multiple of 32 under a multi-tap gather, unaligned rows): the caller then uses the fp32 kernel.
+bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
+    if (!p.b_nk) return false;
+    const int taps = p.KH * p.KW, Ctot = p.C1 + p.C2;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    bool fast = (taps == 1 ? (p.C2 == 0 ? (Ctot % 4 == 0 || p.lda1 >= (Ctot + 3) / 4 * 4)
+                                        : (p.C1 % BK == 0 && Ctot % 4 == 0))
+                           : (Ctot % BK == 0 && p.C1 % BK == 0)) &&
+                p.lda1 % 4 == 0 && al16(p.a1) && p.a_so % 4 == 0 && p.a_si % 4 == 0;
+    if (p.C2 > 0) fast = fast && p.lda2 % 4 == 0 && al16(p.a2);
+    fast = fast && p.ldb % 4 == 0 && al16(p.b) && p.b_so % 4 == 0 && p.b_si % 4 == 0 && p.ldb >= (p.K + 3) / 4 * 4;
+    if (!fast || p.K != taps * Ctot || (p.a_act != 0 && p.a_act != 1)) return false;
+    const int ncols = p.N * (p.geglu ? 2 : 1);
+    const int Nb = ncols;       // rows of B that exist
+    int cfg;
+    if (p.geglu) {
+        if (ncols % 64 != 0) return false;
+        cfg = 0;
+    } else if (ncols <= 32) {
+        cfg = 3;
+    } else {
+        const double c128 = tile_cost(p.M, ncols, p.Z, 128, 128, 1.00);
+        const double c12864 = tile_cost(p.M, ncols, p.Z, 128, 64, 0.90);
+        const double c64 = tile_cost(p.M, ncols, p.Z, 64, 64, 0.75);
+        cfg = (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
+    }
+    const double flops = 2.0 * p.M * (double)ncols * p.K * p.Z;
+    const double bytes = 4.0 * ((double)p.K * ncols + (double)p.M * p.N * p.Z);
+    static const char* kNames3[4] = {"igemm_bf16x3<128x128>", "igemm_bf16x3<128x64>", "igemm_bf16x3<64x64>", "igemm_bf16x3<256x32>"};
+    static const char* kNames1[4] = {"igemm_bf16<128x128>", "igemm_bf16<128x64>", "igemm_bf16<64x64>", "igemm_bf16<256x32>"};
+    char shape_name[48];
+    const char* pname = terms == 3 ? kNames3[cfg] : kNames1[cfg];
+    if (ctx.prof && ctx.prof->detail) {
+        std::snprintf(shape_name, sizeof(shape_name), "bg%d M%d N%d K%d t%d Z%d", cfg, p.M, ncols, p.K, taps, p.Z);
+        pname = shape_name;
+    }
+    ProfScope prof(ctx, pname, flops, bytes);
+    if (terms == 3)
+        launch_terms<3>(ctx, p, cfg, Nb);
+    else
+        launch_terms<1>(ctx, p, cfg, Nb);
+    MAA_HIP(hipGetLastError());
+    return true;
+}
+
+}  // namespace maa

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
         if (B_NK) {
             const int nrow = (tid >> 2) + 64 * j;
             const int n = n0 + nrow;
-            b_ok[j] = nrow < BN && n < p.N;
+            b_ok[j] = nrow < BN && n < Nb;
             b_ptr[j] = bp + (long long)(b_ok[j] ? n : 0) * p.ldb + kq * 4;
         } else {
             const int idx = tid + NT * j;
@@ -330,8 +330,9 @@ template <int BM, int BN, int WGM, int WGN>
 void launch_cfg(const Ctx& ctx, const IGemm& p, bool generic, int Nb) {
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N * (p.geglu ? 2 : 1) + BN - 1) / BN;
     dim3 grid((unsigned)((long long)mtiles * ntiles), (unsigned)p.Z);
-    if (generic) {
-        MAA_CHECK(!p.b_nk, "generic gather with a transposed B operand");
+    if (generic && p.b_nk) {
+        hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, true, true>), grid, dim3(NT), 0, ctx.stream, p, ntiles, Nb);
+    } else if (generic) {
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, false, true>), grid, dim3(NT), 0, ctx.stream, p, ntiles, Nb);
     } else if (p.b_nk) {
         hipLaunchKernelGGL((igemm_f32_kernel<BM, BN, WGM, WGN, true, false>), grid, dim3(NT), 0, ctx.stream, p, ntiles, Nb);
@@ -353,6 +354,10 @@ void launch_igemm(const Ctx& ctx, const IGemm& p_in) {
     IGemm p = p_in;
     p.zeros = ctx.zeros;
     MAA_CHECK(p.zeros != nullptr, "context has no zero page");
+    // precision mode of the context: 1 = bf16x3 split, 2 = plain bf16 operands; problems the bf16 engine cannot
+    // take (B not k-contiguous, odd channel counts) run on the exact-fp32 kernel below
+    if (ctx.dtype == 1 && launch_igemm_bf16(ctx, p, 3)) return;
+    if (ctx.dtype == 2 && launch_igemm_bf16(ctx, p, 1)) return;
     MAA_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty igemm");
     const int taps = p.KH * p.KW, Ctot = p.C1 + p.C2;
     MAA_CHECK(p.K <= taps * Ctot && p.K > (taps - 1) * Ctot, "igemm K mismatch");
@@ -376,7 +381,7 @@ void launch_igemm(const Ctx& ctx, const IGemm& p_in) {
         Nb = (ncols + 3) / 4 * 4;
         if (Nb > p.ldb) Nb = p.ldb / 4 * 4;
     } else {
-        MAA_CHECK(p.K % 4 == 0, "B [N][K] needs K % 4 == 0");
+        MAA_CHECK(p.ldb >= (p.K + 3) / 4 * 4, "B [N][K] rows must be padded to a multiple of 4");
     }
     // algorithmic work of this launch: 2*M*N*K per batch entry (GEGLU computes 2N columns)
     const double flops = 2.0 * p.M * (double)ncols * p.K * p.Z;

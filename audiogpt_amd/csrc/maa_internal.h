@@ -129,6 +129,7 @@ struct IGemm {
     const float* zeros = nullptr;    // >= 16 B of zeros in device memory (filled in by launch_igemm)
 };
 void launch_igemm(const Ctx& ctx, const IGemm& p);
+bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms);   // false: not eligible, use the fp32 kernel
 
 // ------------------------------------------------------------------------------------------ norms etc.
 // GroupNorm(32 groups) over a channels-last tensor given as a virtual concat of two sources; writes
@@ -173,16 +174,22 @@ struct HostTensor {
 };
 using StateDict = std::map<std::string, HostTensor>;
 
-// device-resident packed weight for the igemm B operand: [K][Npad] fp32
+// device-resident packed weight for the igemm B operand, fp32:
+//   nk = 0: [K][Npad] (row pitch ld = Npad)    -- exact-fp32 mode
+//   nk = 1: [Npad][Kpad] (row pitch ld = K rounded up to 4, zero padded) -- bf16 modes (k-contiguous operands)
 struct PackedW {
-    float* w = nullptr;     // [K][Npad]
+    float* w = nullptr;
     float* bias = nullptr;  // [Npad] or null
     int K = 0, N = 0, Npad = 0;
+    int ld = 0, nk = 0;
 };
 
 class WeightStore {
 public:
+    explicit WeightStore(bool nk_layout = false) : nk_(nk_layout) {}
     ~WeightStore();
+    // upload a host [K][Npad] matrix in this store's layout and fill w / ld / nk
+    void finish(PackedW& pw, const std::vector<float>& kn);
     float* upload(const std::vector<float>& host);
     // conv / linear weight [Cout][Cin][KH][KW] (linear: KH=KW=1) -> [ (ky,kx,ci) ][Cout pad 32]
     PackedW pack_conv(const StateDict& sd, const std::string& wname, const std::string& bname, int KH, int KW);
@@ -200,6 +207,7 @@ public:
 private:
     std::vector<void*> bufs_;
     size_t bytes_ = 0;
+    bool nk_ = false;
 };
 
 const HostTensor& get(const StateDict& sd, const std::string& name);

@@ -7,7 +7,9 @@ namespace maa {
 
 class UNet {
 public:
-    UNet(const maa_unet_config& cfg, const StateDict& sd);
+    // precision: 0 exact fp32 MFMA, 1 bf16x3 split, 2 plain bf16 operands (fixed at creation: it decides the
+    // packed weight layout)
+    UNet(const maa_unet_config& cfg, const StateDict& sd, int precision);
     ~UNet();
     void set_context(Ctx& ctx, const float* d_context, int B, int L);
     void forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
@@ -24,7 +26,7 @@ private:
 
 class VAE {
 public:
-    VAE(const maa_vae_config& cfg, const StateDict& sd);
+    VAE(const maa_vae_config& cfg, const StateDict& sd, int precision);
     ~VAE();
     void decode(Ctx& ctx, const float* z_nchw, int B, int h, int w, float inv_scale, float* mel_nchw);
     void encode_moments(Ctx& ctx, const float* mel_nchw, int B, int H, int W, float* moments_nchw);
@@ -37,7 +39,7 @@ private:
 
 class Vocoder {
 public:
-    Vocoder(const maa_vocoder_config& cfg, const StateDict& sd);
+    Vocoder(const maa_vocoder_config& cfg, const StateDict& sd, int precision);
     ~Vocoder();
     void forward(Ctx& ctx, const float* mel, int B, int T, float* wav);
     int hop() const;

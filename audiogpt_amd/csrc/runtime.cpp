@@ -115,6 +115,22 @@ float* WeightStore::vec(const StateDict& sd, const std::string& name) {
 
 static int pad32(int n) { return (n + 31) / 32 * 32; }
 
+void WeightStore::finish(PackedW& pw, const std::vector<float>& kn) {
+    if (!nk_) {
+        pw.w = upload(kn);
+        pw.ld = pw.Npad;
+        pw.nk = 0;
+        return;
+    }
+    const int Kp = (pw.K + 3) / 4 * 4;
+    std::vector<float> t((size_t)pw.Npad * Kp, 0.f);
+    for (int k = 0; k < pw.K; ++k)
+        for (int n = 0; n < pw.Npad; ++n) t[(size_t)n * Kp + k] = kn[(size_t)k * pw.Npad + n];
+    pw.w = upload(t);
+    pw.ld = Kp;
+    pw.nk = 1;
+}
+
 PackedW WeightStore::pack_conv(const StateDict& sd, const std::string& wname, const std::string& bname, int KH,
                                int KW) {
     const HostTensor& w = get(sd, wname);
@@ -130,7 +146,7 @@ PackedW WeightStore::pack_conv(const StateDict& sd, const std::string& wname, co
         for (int ci = 0; ci < Cin; ++ci)
             for (int t = 0; t < KH * KW; ++t)
                 h[((size_t)t * Cin + ci) * pw.Npad + co] = w.data[((size_t)co * Cin + ci) * KH * KW + t];
-    pw.w = upload(h);
+    finish(pw, h);
     if (!bname.empty()) {
         const HostTensor& b = get(sd, bname);
         std::vector<float> hb(pw.Npad, 0.f);
@@ -167,7 +183,7 @@ PackedW WeightStore::pack_concat(const StateDict& sd, const std::vector<std::str
         }
         col += co_n;
     }
-    pw.w = upload(h);
+    finish(pw, h);
     bool any_bias = false;
     for (auto& b : bnames) any_bias = any_bias || !b.empty();
     if (any_bias) pw.bias = upload(hb);
@@ -197,7 +213,7 @@ PackedW WeightStore::pack_geglu(const StateDict& sd, const std::string& wname, c
         hb[cv] = b.data[j];
         hb[cg] = b.data[inner + j];
     }
-    pw.w = upload(h);
+    finish(pw, h);
     pw.bias = upload(hb);
     return pw;
 }
@@ -235,7 +251,7 @@ PackedW WeightStore::pack_convtr_phase(const StateDict& sd, const std::string& w
         }
         for (int co = 0; co < Cout; ++co) hb[ri * Cout + co] = b.data[co];
     }
-    pw.w = upload(h);
+    finish(pw, h);
     pw.bias = upload(hb);
     return pw;
 }

@@ -56,7 +56,9 @@ struct Layer {
 
 struct UNet::Impl {
     maa_unet_config cfg;
+    int precision = 0;
     WeightStore ws;
+    explicit Impl(int prec) : precision(prec), ws(prec != 0) {}
     std::vector<ResW> res;
     std::vector<STW> st;
     std::vector<AttnW> attn;
@@ -449,7 +451,7 @@ struct UNet::Impl {
     }
 };
 
-UNet::UNet(const maa_unet_config& cfg, const StateDict& sd) : impl_(new Impl) {
+UNet::UNet(const maa_unet_config& cfg, const StateDict& sd, int precision) : impl_(new Impl(precision)) {
     impl_->cfg = cfg;
     impl_->build(sd);
 }
@@ -460,6 +462,7 @@ size_t UNet::weight_bytes() const { return impl_->ws.bytes(); }
 void UNet::set_context(Ctx& ctx, const float* context, int B, int L) {
     Impl& m = *impl_;
     if (!m.cfg.use_spatial_transformer) return;
+    PrecisionGuard pg(ctx, m.precision);
     const size_t rows = (size_t)B * L;
     if (rows > m.kv_cap_rows) {
         for (size_t i = 0; i < m.kv_cache.size(); ++i) {
@@ -482,6 +485,7 @@ void UNet::set_context(Ctx& ctx, const float* context, int B, int L) {
 void UNet::forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
                    float* out_nchw) {
     Impl& m = *impl_;
+    PrecisionGuard pg(ctx, m.precision);
     run_sized(ctx, [&] { m.forward(ctx, x_nchw, t, context, B, H, W, out_nchw); });
 }
 

@@ -35,7 +35,9 @@ struct VLevel {
 
 struct VAE::Impl {
     maa_vae_config cfg;
+    int precision = 0;
     WeightStore ws;
+    explicit Impl(int prec) : precision(prec), ws(prec != 0) {}
     bool has_encoder = false;
     // decoder
     PackedW d_conv_in, d_conv_out, post_quant;
@@ -275,7 +277,7 @@ struct VAE::Impl {
     }
 };
 
-VAE::VAE(const maa_vae_config& cfg, const StateDict& sd) : impl_(new Impl) {
+VAE::VAE(const maa_vae_config& cfg, const StateDict& sd, int precision) : impl_(new Impl(precision)) {
     impl_->cfg = cfg;
     impl_->build(sd);
 }
@@ -283,9 +285,11 @@ VAE::~VAE() { delete impl_; }
 const maa_vae_config& VAE::config() const { return impl_->cfg; }
 
 void VAE::decode(Ctx& ctx, const float* z, int B, int h, int w, float inv_scale, float* mel) {
+    PrecisionGuard pg(ctx, impl_->precision);
     run_sized(ctx, [&] { impl_->decode(ctx, z, B, h, w, inv_scale, mel); });
 }
 void VAE::encode_moments(Ctx& ctx, const float* mel, int B, int H, int W, float* moments) {
+    PrecisionGuard pg(ctx, impl_->precision);
     run_sized(ctx, [&] { impl_->encode(ctx, mel, B, H, W, moments); });
 }
 

@@ -72,7 +72,9 @@ void fold_weight_norm(const StateDict& in, Folded& out) {
 
 struct Vocoder::Impl {
     maa_vocoder_config cfg;
+    int precision = 0;
     WeightStore ws;
+    explicit Impl(int prec) : precision(prec), ws(prec != 0) {}
     PackedW conv_pre, conv_post;
     std::vector<UpW> ups;
     std::vector<ResBlockW> rbs;
@@ -210,7 +212,8 @@ struct Vocoder::Impl {
                     p.a_slope = 0.1f;
                 }
                 p.b = u.ph[gi].w;
-                p.ldb = u.ph[gi].Npad;
+                p.ldb = u.ph[gi].ld;
+                p.b_nk = u.ph[gi].nk;
                 p.M = B * L;
                 p.K = U * u.cin;
                 p.N = u.r_count[gi] * u.cout;
@@ -278,7 +281,7 @@ struct Vocoder::Impl {
     }
 };
 
-Vocoder::Vocoder(const maa_vocoder_config& cfg, const StateDict& sd) : impl_(new Impl) {
+Vocoder::Vocoder(const maa_vocoder_config& cfg, const StateDict& sd, int precision) : impl_(new Impl(precision)) {
     impl_->cfg = cfg;
     impl_->build(sd);
 }
@@ -286,6 +289,7 @@ Vocoder::~Vocoder() { delete impl_; }
 int Vocoder::hop() const { return impl_->hop; }
 
 void Vocoder::forward(Ctx& ctx, const float* mel, int B, int T, float* wav) {
+    PrecisionGuard pg(ctx, impl_->precision);
     run_sized(ctx, [&] { impl_->forward(ctx, mel, B, T, wav); });
 }
 

@@ -38,10 +38,11 @@ class MakeAnAudio:
     """UNet + VAE + vocoder replicas on one device."""
 
     def __init__(self, device="cuda:0", ldm=None, vocoder_cfg=None, unet_sd=None, vae_sd=None, vocoder_sd=None,
-                 seeds=(0, 1, 2), with_encoder=False):
+                 seeds=(0, 1, 2), with_encoder=False, precision="f32"):
         self.ldm = ldm or C.LDM_T2A
         self.vocoder_cfg = vocoder_cfg or C.HIFIGAN_16K
-        self.ctx = Context(device)
+        self.precision = precision
+        self.ctx = Context(device, precision=precision)
         self.device = self.ctx.device
         unet_sd = unet_sd if unet_sd is not None else WT.make_unet_state_dict(self.ldm["unet"], seed=seeds[0])
         vae_sd = vae_sd if vae_sd is not None else WT.make_vae_state_dict(self.ldm["vae"], seed=seeds[1],

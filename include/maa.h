@@ -51,6 +51,14 @@ int maa_ctx_create(int device_id, void* hip_stream, maa_ctx** out);
 int maa_ctx_destroy(maa_ctx* ctx);
 int maa_ctx_synchronize(maa_ctx* ctx);
 int maa_ctx_set_stream(maa_ctx* ctx, void* hip_stream);
+/* Arithmetic of the contractions for models CREATED after this call (it fixes their packed weight layout) and
+ * for the maa_op_* entry points:
+ *   0  exact fp32: v_mfma_f32_32x32x2_f32, bit-for-bit a k-ordered fmaf chain (default)
+ *   1  bf16x3: fp32 operands split on the fly into bf16 hi + lo, lo*hi + hi*lo + hi*hi on the bf16 MFMA with fp32
+ *      accumulation (~2^-16 per product; meets the fp32 parity gates at 5.3x the fp32 MFMA rate)
+ *   2  bf16: operands rounded to bf16, fp32 accumulation (throughput mode, error reported not gated)
+ * Storage, normalisations, softmax and every epilogue stay fp32 in all modes. */
+int maa_ctx_set_precision(maa_ctx* ctx, int mode);
 /* bytes currently reserved for the activation workspace */
 int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out);
 

@@ -11,8 +11,9 @@ from audiogpt_amd.pipeline import MakeAnAudio  # noqa: E402
 from bench import synth_conditioning, LATENT, CFG_SCALE  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f32"
 n = 8
-pipe = MakeAnAudio("cuda:0")
+pipe = MakeAnAudio("cuda:0", precision=PREC)
 x_T = torch.from_numpy(np.random.RandomState(55).randn(n, *LATENT)).float().cuda()
 c = synth_conditioning(n, 1234).cuda()
 uc = synth_conditioning(1, 1235).cuda().expand(n, -1, -1).contiguous()
