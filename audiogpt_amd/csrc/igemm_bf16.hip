@@ -303,10 +303,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     } else if (ncols <= 32) {
         cfg = 3;
     } else {
-        const double c128 = tile_cost(p.M, ncols, p.Z, 128, 128, 1.00);
-        const double c12864 = tile_cost(p.M, ncols, p.Z, 128, 64, 0.90);
-        const double c64 = tile_cost(p.M, ncols, p.Z, 64, 64, 0.75);
-        cfg = (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
+        cfg = choose_tile(p.M, ncols, p.Z, true);
     }
     const double flops = 2.0 * p.M * (double)ncols * p.K * p.Z;
     const double bytes = 4.0 * ((double)p.K * ncols + (double)p.M * p.N * p.Z);

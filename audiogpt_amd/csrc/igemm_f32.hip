@@ -393,10 +393,7 @@ void launch_igemm(const Ctx& ctx, const IGemm& p_in) {
     } else if (ncols <= 32) {
         cfg = 3;
     } else {
-        const double c128 = tile_cost(p.M, ncols, p.Z, 128, 128, 1.00);
-        const double c12864 = tile_cost(p.M, ncols, p.Z, 128, 64, 0.92);
-        const double c64 = tile_cost(p.M, ncols, p.Z, 64, 64, 0.80);
-        cfg = (c128 <= c12864 && c128 <= c64) ? 0 : (c12864 <= c64 ? 1 : 2);
+        cfg = choose_tile(p.M, ncols, p.Z, false);
     }
     static const char* kNames[4] = {"igemm_f32<128x128>", "igemm_f32<128x64>", "igemm_f32<64x64>", "igemm_f32<256x32>"};
     char shape_name[48];

@@ -129,6 +129,10 @@ struct IGemm {
     const float* zeros = nullptr;    // >= 16 B of zeros in device memory (filled in by launch_igemm)
 };
 void launch_igemm(const Ctx& ctx, const IGemm& p);
+// Tile choice shared by the fp32 and bf16 engines: 0 = 128x128, 1 = 128x64, 2 = 64x64 (3 = 256x32 is chosen by
+// the callers for N <= 32).  Cost = CU-rounds x tile area / (tile efficiency x latency hiding at that many
+// co-resident blocks per CU); knobs can be overridden for tuning with MAA_TILE_EFF / MAA_CONC_EFF / MAA_FORCE_CFG.
+int choose_tile(long long M, long long N, int Z, bool bf16);
 bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms);   // false: not eligible, use the fp32 kernel
 
 // ------------------------------------------------------------------------------------------ norms etc.

@@ -6,6 +6,7 @@
 //   ConvTranspose1d [Cin][Cout][k]  (NeuralSeq/modules/hifigan/hifigan.py:121-125)
 #include "maa_internal.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace maa {
@@ -85,6 +86,39 @@ ProfScope::ProfScope(const Ctx& ctx, const char* name, double flops, double byte
 }
 ProfScope::~ProfScope() {
     if (ctx_) (void)hipEventRecord(ctx_->prof->pending[idx_].e1, ctx_->stream);
+}
+
+// ------------------------------------------------------------------------------------------ tile choice
+namespace {
+struct TileKnobs {
+    double eff[3] = {1.00, 0.92, 0.80};       // per-block efficiency of 128x128 / 128x64 / 64x64
+    double conc[3] = {0.55, 0.85, 1.00};      // latency hiding with 1 / 2 / >=3 co-resident blocks per CU
+    int force = -1;
+    TileKnobs() {
+        if (const char* e = std::getenv("MAA_TILE_EFF")) std::sscanf(e, "%lf,%lf,%lf", &eff[0], &eff[1], &eff[2]);
+        if (const char* e = std::getenv("MAA_CONC_EFF")) std::sscanf(e, "%lf,%lf,%lf", &conc[0], &conc[1], &conc[2]);
+        if (const char* e = std::getenv("MAA_FORCE_CFG")) force = std::atoi(e);
+    }
+};
+}  // namespace
+int choose_tile(long long M, long long N, int Z, bool bf16) {
+    static const TileKnobs k;
+    if (k.force >= 0 && k.force <= 2) return k.force;
+    static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+    const int max_occ[3] = {bf16 ? 2 : 3, bf16 ? 2 : 4, 4};   // blocks per CU allowed by LDS / registers
+    int best = 0;
+    double best_cost = 1e300;
+    for (int c = 0; c < 3; ++c) {
+        const long long blocks = ((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]) * Z;
+        const long long per_cu = (blocks + 255) / 256;
+        const int co = (int)(per_cu < max_occ[c] ? per_cu : max_occ[c]);
+        const double cost = (double)per_cu * bm[c] * bn[c] / (k.eff[c] * k.conc[co >= 3 ? 2 : co - 1]);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
 }
 
 // ------------------------------------------------------------------------------------------ StateDict helpers

@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=DDIM_STEPS)
     ap.add_argument("--prompts-per-gpu", type=int, default=PROMPTS_PER_GPU)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
+                    help="contraction arithmetic: exact fp32 MFMA, bf16x3 split (default; meets the fp32 parity gates), bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table of one profiled batch to stderr")
@@ -117,7 +119,7 @@ def main():
 
     from audiogpt_amd.pipeline import MakeAnAudio
     from audiogpt_amd.shard import broadcast_conditioning, gather_waveforms
-    pipe = MakeAnAudio(dev)
+    pipe = MakeAnAudio(dev, precision=args.precision)
     n = args.prompts_per_gpu
     S = args.ddim_steps
     use_graph = not args.no_graph
