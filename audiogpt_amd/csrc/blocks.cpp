@@ -29,6 +29,13 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
     p.b = w.w;
     p.ldb = w.ld;
     p.b_nk = w.nk;
+    p.b_split = w.split;
+    p.b_lo_off = w.lo_off;
+    if (x1.split) {
+        MAA_CHECK(!x2, "a split source cannot be concatenated");
+        p.a_split = 1;
+        p.a_lo_off = x1.numel();
+    }
     p.M = out.B * out.H * out.W;
     p.K = o.KH * o.KW * (p.C1 + p.C2);
     MAA_CHECK(p.K == w.K, "conv weight K mismatch");
@@ -49,7 +56,7 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
 }
 
 void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const PackedW& w, const float* res,
-                 int ldr, float* out, int ldc, int geglu, int a_act) {
+                 int ldr, float* out, int ldc, int geglu, int a_act, long long a_split_rows) {
     IGemm p;
     p.a1 = a;
     p.lda1 = lda;
@@ -63,6 +70,12 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
     p.b = w.w;
     p.ldb = w.ld;
     p.b_nk = w.nk;
+    p.b_split = w.split;
+    p.b_lo_off = w.lo_off;
+    if (a_split_rows > 0) {
+        p.a_split = 1;
+        p.a_lo_off = a_split_rows * (long long)lda;
+    }
     p.bias = w.bias;
     p.res = res;
     p.ldr = ldr;

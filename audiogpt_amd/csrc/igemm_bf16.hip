@@ -38,14 +38,28 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     lo = pk_bf16(a - fa, b - fb);
 }
 
-template <int BM, int BN, int WGM, int WGN, int TERMS>
+// A_SPLIT / B_SPLIT: the operand already sits in memory as two bf16 planes (hi, then lo at +lo_off elements), k
+// contiguous: GroupNorm / LayerNorm outputs and packed weights in the bf16 modes.  Its tile is then copied
+// global -> LDS as 16-byte pieces with no conversion; otherwise the operand is fp32 and is split while its tile is
+// written to LDS (once per tile, i.e. once per tap and per N-tile for a conv -- which is why producers pre-split).
+__device__ __forceinline__ void st16(unsigned short* dst, const float4& v) {   // 16-byte LDS store, by members
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    *reinterpret_cast<f32x4*>(dst) = t;
+}
+
+template <int BM, int BN, int WGM, int WGN, int TERMS, bool A_SPLIT, bool B_SPLIT>
 __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntiles, int Nb) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
-    constexpr int AL = BM / 32, BL = BN / 32;          // float4 per thread per chunk
     constexpr int PLANES = TERMS == 1 ? 1 : 2;
     constexpr int ROWS = BM + BN;
     constexpr int PLANE_ELEMS = ROWS * LDK;            // bf16 elements of one plane of one buffer
+    // per-thread 16-byte loads per chunk: fp32 operand: rows/32 float4; split operand: (rows/64 row slots) x planes
+    constexpr int ARS = A_SPLIT ? (BM >= 64 ? BM / 64 : 1) : BM / 32;       // row slots of this thread
+    constexpr int BRS = B_SPLIT ? (BN >= 64 ? BN / 64 : 1) : BN / 32;
+    constexpr int AL = A_SPLIT ? ARS * PLANES : ARS;
+    constexpr int BL = B_SPLIT ? BRS * PLANES : BRS;
     static_assert(WGM * WGN == 4 && BM % 32 == 0 && BN % 32 == 0, "tile");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // [buf][plane][row][LDK]
 
@@ -58,6 +72,8 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     const float* a1 = p.a1 + zo * p.a_so + zi * p.a_si;
     const float* a2 = p.a2;
     const float* bp = p.b + zo * p.b_so + zi * p.b_si;
+    const unsigned short* a_hi = reinterpret_cast<const unsigned short*>(p.a1);
+    const unsigned short* b_hi = reinterpret_cast<const unsigned short*>(p.b);
     const long long coff = zo * p.c_so + zi * p.c_si;
 
     const int Ctot = p.C1 + p.C2;
@@ -67,13 +83,19 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     const float4* g_zero4 = reinterpret_cast<const float4*>(p.zeros);
     const float slope = p.a_act == 1 ? p.a_slope : 1.0f;
 
-    // ---- per-thread A rows
-    const int kq = tid & 7, trow = tid >> 3;
-    int a_b[AL], a_iy0[AL], a_ix0[AL];
+    // thread -> (row slot, k offset) for each operand form
+    const int a_r0 = A_SPLIT ? (tid >> 2) : (tid >> 3), a_rstep = A_SPLIT ? 64 : 32;
+    const int a_k = A_SPLIT ? (tid & 3) * 8 : (tid & 7) * 4;
+    const int b_r0 = B_SPLIT ? (tid >> 2) : (tid >> 3), b_rstep = B_SPLIT ? 64 : 32;
+    const int b_k = B_SPLIT ? (tid & 3) * 8 : (tid & 7) * 4;
+
+    // ---- A rows of this thread
+    int a_b[ARS], a_iy0[ARS], a_ix0[ARS];
 #pragma unroll
-    for (int j = 0; j < AL; ++j) {
-        const int m = m0 + trow + 32 * j;
-        if (m < p.M) {
+    for (int j = 0; j < ARS; ++j) {
+        const int row = a_r0 + a_rstep * j;
+        const int m = m0 + row;
+        if (row < BM && m < p.M) {
             const int b = m / rpb;
             const int rem = m - b * rpb;
             const int oy = rem / p.Wout;
@@ -87,32 +109,50 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
             a_ix0[j] = 0;
         }
     }
-    const float* a_p1[AL];
-    const float* a_p2[AL];
-    bool a_ok[AL];
+    const void* a_p1[ARS];
+    const void* a_p2[ARS];
+    bool a_ok[ARS];
     int g_tap = 0, g_ci = 0;
     auto set_tap = [&](int tap) {
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
 #pragma unroll
-        for (int j = 0; j < AL; ++j) {
+        for (int j = 0; j < ARS; ++j) {
             int iy = a_iy0[j] + ky * p.dh, ix = a_ix0[j] + kx * p.dw;
             const bool ok = a_b[j] >= 0 && iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim;
             iy >>= p.up;
             ix >>= p.up;
             const long long off = ok ? ((long long)a_b[j] * p.Hin + iy) * p.Win + ix : 0;
             a_ok[j] = ok;
-            a_p1[j] = a1 + off * p.lda1 + kq * 4;
-            a_p2[j] = a2 + off * p.lda2 + kq * 4 - p.C1;
+            if constexpr (A_SPLIT) {
+                a_p1[j] = a_hi + off * p.lda1 + a_k;
+                a_p2[j] = nullptr;
+            } else {
+                a_p1[j] = a1 + off * p.lda1 + a_k;
+                a_p2[j] = a2 + off * p.lda2 + a_k - p.C1;
+            }
         }
     };
     auto load_a = [&](float4 (&ra)[AL]) {
-        const bool first = g_ci < p.C1;
-        const int cend = first ? p.C1 : Ctot;
-        const bool kin = g_ci + kq * 4 < cend;
+        if constexpr (A_SPLIT) {
+            const bool kin = g_ci + a_k < Ctot;
 #pragma unroll
-        for (int j = 0; j < AL; ++j) {
-            const float4* src = reinterpret_cast<const float4*>((first ? a_p1[j] : a_p2[j]) + g_ci);
-            ra[j] = *((a_ok[j] && kin) ? src : g_zero4);
+            for (int q = 0; q < AL; ++q) {
+                const int pl = q / ARS, j = q % ARS;
+                const float4* src = reinterpret_cast<const float4*>(
+                    static_cast<const unsigned short*>(a_p1[j]) + pl * p.a_lo_off + g_ci);
+                const float4 v = *((a_ok[j] && kin) ? src : g_zero4);   // (a local first: a direct struct copy
+                ra[q] = v;                                               //  into the array defeats SROA -> scratch)
+            }
+        } else {
+            const bool first = g_ci < p.C1;
+            const int cend = first ? p.C1 : Ctot;
+            const bool kin = g_ci + a_k < cend;
+#pragma unroll
+            for (int j = 0; j < ARS; ++j) {
+                const float4* src = reinterpret_cast<const float4*>(
+                    static_cast<const float*>(first ? a_p1[j] : a_p2[j]) + g_ci);
+                ra[j] = *((a_ok[j] && kin) ? src : g_zero4);
+            }
         }
         g_ci += BK;
         if (g_ci >= Ctot && g_tap + 1 < taps) {
@@ -123,59 +163,84 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     };
 
     // ---- B rows ([N][K], k contiguous)
-    const float* b_ptr[BL];
-    bool b_ok[BL];
+    const void* b_ptr[BRS];
+    bool b_ok[BRS];
 #pragma unroll
-    for (int j = 0; j < BL; ++j) {
-        const int n = n0 + trow + 32 * j;
-        b_ok[j] = n < Nb;
-        b_ptr[j] = bp + (long long)(b_ok[j] ? n : 0) * p.ldb + kq * 4;
+    for (int j = 0; j < BRS; ++j) {
+        const int row = b_r0 + b_rstep * j;
+        const int n = n0 + row;
+        b_ok[j] = row < BN && n < Nb;
+        if constexpr (B_SPLIT)
+            b_ptr[j] = b_hi + (long long)(b_ok[j] ? n : 0) * p.ldb + b_k;
+        else
+            b_ptr[j] = bp + (long long)(b_ok[j] ? n : 0) * p.ldb + b_k;
     }
     auto load_b = [&](float4 (&rb)[BL], int k0) {
+        const bool kin = k0 + b_k < p.K;
+        if constexpr (B_SPLIT) {
 #pragma unroll
-        for (int j = 0; j < BL; ++j) {
-            const float4* src = reinterpret_cast<const float4*>(b_ptr[j] + k0);
-            rb[j] = *((b_ok[j] && k0 + kq * 4 < p.K) ? src : g_zero4);
+            for (int q = 0; q < BL; ++q) {
+                const int pl = q / BRS, j = q % BRS;
+                const float4* src = reinterpret_cast<const float4*>(
+                    static_cast<const unsigned short*>(b_ptr[j]) + pl * p.b_lo_off + k0);
+                const float4 v = *((b_ok[j] && kin) ? src : g_zero4);
+                rb[q] = v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BRS; ++j) {
+                const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(b_ptr[j]) + k0);
+                rb[j] = *((b_ok[j] && kin) ? src : g_zero4);
+            }
         }
     };
 
+    // fp32 float4 (4 k) -> hi / lo words at LDS element offset e
+    auto put_f32 = [&](unsigned short* base, int e, float4 v) {
+        uint2 hi, lo;
+        if constexpr (TERMS == 1) {
+            hi.x = pk_bf16(v.x, v.y);
+            hi.y = pk_bf16(v.z, v.w);
+            *reinterpret_cast<uint2*>(base + e) = hi;
+        } else {
+            split2(v.x, v.y, hi.x, lo.x);
+            split2(v.z, v.w, hi.y, lo.y);
+            *reinterpret_cast<uint2*>(base + e) = hi;
+            *reinterpret_cast<uint2*>(base + PLANE_ELEMS + e) = lo;
+        }
+    };
     auto store_tiles = [&](const float4 (&ra)[AL], const float4 (&rb)[BL], int buf) {
         unsigned short* base = smem + buf * PLANES * PLANE_ELEMS;
+        if constexpr (A_SPLIT) {
 #pragma unroll
-        for (int j = 0; j < AL; ++j) {
-            float4 v = ra[j];
-            v.x = fmaxf(v.x, v.x * slope);
-            v.y = fmaxf(v.y, v.y * slope);
-            v.z = fmaxf(v.z, v.z * slope);
-            v.w = fmaxf(v.w, v.w * slope);
-            const int e = (trow + 32 * j) * LDK + kq * 4;
-            uint2 hi, lo;
-            if constexpr (TERMS == 1) {
-                hi.x = pk_bf16(v.x, v.y);
-                hi.y = pk_bf16(v.z, v.w);
-                *reinterpret_cast<uint2*>(base + e) = hi;
-            } else {
-                split2(v.x, v.y, hi.x, lo.x);
-                split2(v.z, v.w, hi.y, lo.y);
-                *reinterpret_cast<uint2*>(base + e) = hi;
-                *reinterpret_cast<uint2*>(base + PLANE_ELEMS + e) = lo;
+            for (int q = 0; q < AL; ++q) {
+                const int pl = q / ARS, j = q % ARS;
+                const int row = a_r0 + a_rstep * j;
+                if (BM >= 64 || row < BM)
+                    st16(base + pl * PLANE_ELEMS + row * LDK + a_k, ra[q]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < ARS; ++j) {
+                float4 v = ra[j];
+                v.x = fmaxf(v.x, v.x * slope);
+                v.y = fmaxf(v.y, v.y * slope);
+                v.z = fmaxf(v.z, v.z * slope);
+                v.w = fmaxf(v.w, v.w * slope);
+                put_f32(base, (a_r0 + a_rstep * j) * LDK + a_k, v);
             }
         }
+        if constexpr (B_SPLIT) {
 #pragma unroll
-        for (int j = 0; j < BL; ++j) {
-            const float4 v = rb[j];
-            const int e = (BM + trow + 32 * j) * LDK + kq * 4;
-            uint2 hi, lo;
-            if constexpr (TERMS == 1) {
-                hi.x = pk_bf16(v.x, v.y);
-                hi.y = pk_bf16(v.z, v.w);
-                *reinterpret_cast<uint2*>(base + e) = hi;
-            } else {
-                split2(v.x, v.y, hi.x, lo.x);
-                split2(v.z, v.w, hi.y, lo.y);
-                *reinterpret_cast<uint2*>(base + e) = hi;
-                *reinterpret_cast<uint2*>(base + PLANE_ELEMS + e) = lo;
+            for (int q = 0; q < BL; ++q) {
+                const int pl = q / BRS, j = q % BRS;
+                const int row = b_r0 + b_rstep * j;
+                if (BN >= 64 || row < BN)
+                    st16(base + pl * PLANE_ELEMS + (BM + row) * LDK + b_k, rb[q]);
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < BRS; ++j) put_f32(base, (BM + b_r0 + b_rstep * j) * LDK + b_k, rb[j]);
         }
     };
 
@@ -247,14 +312,14 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     igemm_epilogue<MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lrow, lk, coff, Nb, rpb);
 }
 
-template <int BM, int BN, int WGM, int WGN, int TERMS>
+template <int BM, int BN, int WGM, int WGN, int TERMS, bool AS, bool BS>
 void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
     const int ncols = p.N * (p.geglu ? 2 : 1);
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (ncols + BN - 1) / BN;
     dim3 grid((unsigned)((long long)mtiles * ntiles), (unsigned)p.Z);
     constexpr int planes = TERMS == 1 ? 1 : 2;
     constexpr size_t lds = (size_t)2 * planes * (BM + BN) * LDK * sizeof(unsigned short);
-    auto kern = igemm_bf16_kernel<BM, BN, WGM, WGN, TERMS>;
+    auto kern = igemm_bf16_kernel<BM, BN, WGM, WGN, TERMS, AS, BS>;
     static bool attr_set = false;
     if (!attr_set) {
         MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -263,20 +328,24 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, p, ntiles, Nb);
 }
 
-template <int TERMS>
-void launch_terms(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
+template <int TERMS, bool AS, bool BS>
+void launch_tile(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
     switch (cfg) {
-        case 0: launch_one<128, 128, 2, 2, TERMS>(ctx, p, Nb); break;
-        case 1: launch_one<128, 64, 2, 2, TERMS>(ctx, p, Nb); break;
-        case 2: launch_one<64, 64, 2, 2, TERMS>(ctx, p, Nb); break;
-        default: launch_one<256, 32, 4, 1, TERMS>(ctx, p, Nb); break;
+        case 0: launch_one<128, 128, 2, 2, TERMS, AS, BS>(ctx, p, Nb); break;
+        case 1: launch_one<128, 64, 2, 2, TERMS, AS, BS>(ctx, p, Nb); break;
+        case 2: launch_one<64, 64, 2, 2, TERMS, AS, BS>(ctx, p, Nb); break;
+        default: launch_one<256, 32, 4, 1, TERMS, AS, BS>(ctx, p, Nb); break;
     }
 }
 
-inline double tile_cost(long long M, long long N, int Z, int BM, int BN, double eff) {
-    const long long blocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * Z;
-    const long long rounds = (blocks + 255) / 256;
-    return (double)rounds * BM * BN / eff;
+template <int TERMS>
+void launch_terms(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
+    if (p.a_split && p.b_split)
+        launch_tile<TERMS, true, true>(ctx, p, cfg, Nb);
+    else if (p.b_split)
+        launch_tile<TERMS, false, true>(ctx, p, cfg, Nb);
+    else
+        launch_tile<TERMS, false, false>(ctx, p, cfg, Nb);
 }
 
 }  // namespace
@@ -284,16 +353,33 @@ inline double tile_cost(long long M, long long N, int Z, int BM, int BN, double 
 // Returns false when the problem cannot take this path (B not k-contiguous, channel counts that are not a
 // multiple of 32 under a multi-tap gather, unaligned rows): the caller then uses the fp32 kernel.
 bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
-    if (!p.b_nk) return false;
+    if (!p.b_nk) {
+        MAA_CHECK(!p.a_split && !p.b_split, "split operands need the k-contiguous bf16 engine");
+        return false;
+    }
     const int taps = p.KH * p.KW, Ctot = p.C1 + p.C2;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    bool fast = (taps == 1 ? (p.C2 == 0 ? (Ctot % 4 == 0 || p.lda1 >= (Ctot + 3) / 4 * 4)
-                                        : (p.C1 % BK == 0 && Ctot % 4 == 0))
-                           : (Ctot % BK == 0 && p.C1 % BK == 0)) &&
-                p.lda1 % 4 == 0 && al16(p.a1) && p.a_so % 4 == 0 && p.a_si % 4 == 0;
-    if (p.C2 > 0) fast = fast && p.lda2 % 4 == 0 && al16(p.a2);
-    fast = fast && p.ldb % 4 == 0 && al16(p.b) && p.b_so % 4 == 0 && p.b_si % 4 == 0 && p.ldb >= (p.K + 3) / 4 * 4;
-    if (!fast || p.K != taps * Ctot || (p.a_act != 0 && p.a_act != 1)) return false;
+    bool fast;
+    if (p.a_split) {
+        // bf16 planes: 8-element (16-byte) pieces
+        fast = p.C2 == 0 && Ctot % 8 == 0 && (taps == 1 || Ctot % BK == 0) && p.lda1 % 8 == 0 && al16(p.a1) &&
+               p.a_lo_off % 8 == 0 && p.Z == 1 && p.a_act == 0;
+    } else {
+        fast = (taps == 1 ? (p.C2 == 0 ? (Ctot % 4 == 0 || p.lda1 >= (Ctot + 3) / 4 * 4)
+                                       : (p.C1 % BK == 0 && Ctot % 4 == 0))
+                          : (Ctot % BK == 0 && p.C1 % BK == 0)) &&
+               p.lda1 % 4 == 0 && al16(p.a1) && p.a_so % 4 == 0 && p.a_si % 4 == 0;
+        if (p.C2 > 0) fast = fast && p.lda2 % 4 == 0 && al16(p.a2);
+    }
+    if (p.b_split)
+        fast = fast && p.ldb % 8 == 0 && al16(p.b) && p.b_lo_off % 8 == 0 && p.ldb >= (p.K + 7) / 8 * 8 && p.Z == 1;
+    else
+        fast = fast && p.ldb % 4 == 0 && al16(p.b) && p.b_so % 4 == 0 && p.b_si % 4 == 0 && p.ldb >= (p.K + 3) / 4 * 4;
+    fast = fast && p.K == taps * Ctot && (p.a_act == 0 || p.a_act == 1);
+    if (!fast) {
+        MAA_CHECK(!p.a_split && !p.b_split, "split operand given to a problem the bf16 engine cannot take");
+        return false;
+    }
     const int ncols = p.N * (p.geglu ? 2 : 1);
     const int Nb = ncols;       // rows of B that exist
     int cfg;

@@ -102,12 +102,16 @@ struct IGemm {
     int Hin = 1, Win = 1, Hout = 1, Wout = 1;
     int KH = 1, KW = 1, sh = 1, sw = 1, ph = 0, pw = 0, dh = 1, dw = 1;
     int up = 0;                      // 1: source is read through a virtual nearest-2x upsample
-    int a_act = 0;                   // 0 none, 1 leaky-relu(a_slope), 2 silu   (applied while staging A)
+    int a_split = 0;                 // A is two bf16 planes (hi at a1, lo at +a_lo_off ushort elements); lda in ushorts
+    long long a_lo_off = 0;
+    int a_act = 0;                   // 0 none, 1 leaky-relu(a_slope)   (applied while staging an fp32 A)
     float a_slope = 0.f;
     // B operand
     const float* b = nullptr;
     int ldb = 0;
     int b_nk = 0;                    // 0: B stored [K][N] (packed weights, V);  1: stored [N][K] (K^T)
+    int b_split = 0;                 // B is two bf16 planes [N][K] (hi at b, lo at +b_lo_off); ldb in ushorts
+    long long b_lo_off = 0;
     // dims
     int M = 0, N = 0, K = 0;
     // batching over blockIdx.z: z -> (zo, zi) = (z / zin, z % zin)
@@ -138,11 +142,13 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms);   // false: n
 // ------------------------------------------------------------------------------------------ norms etc.
 // GroupNorm(32 groups) over a channels-last tensor given as a virtual concat of two sources; writes
 // a dense [B, HW, C1+C2] tensor.  silu: fuse x*sigmoid(x).
-void launch_groupnorm(const Ctx& ctx, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2,
-                      int B, int HW, int groups, const float* gamma, const float* beta, float eps, int silu,
-                      float* out);
-void launch_layernorm(const Ctx& ctx, const float* x, int rows, int C, const float* gamma, const float* beta,
-                      float eps, float* out);
+// out_split = 1: the output is written as two bf16 planes (hi, then lo at +B*HW*C ushort elements) for a bf16-engine
+// consumer instead of fp32 (same byte size).  Takes 2*B*groups floats of scratch from the arena.
+void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int B, int HW,
+                      int groups, const float* gamma, const float* beta, float eps, int silu, float* out,
+                      int out_split = 0);
+void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, const float* gamma, const float* beta,
+                      float eps, float* out, int out_split = 0);
 // in-place row softmax over `cols` columns of a [rows, ld] matrix; columns [cols, ld) are zeroed
 void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld);
 
@@ -186,6 +192,8 @@ struct PackedW {
     float* bias = nullptr;  // [Npad] or null
     int K = 0, N = 0, Npad = 0;
     int ld = 0, nk = 0;
+    int split = 0;          // 1: w points to bf16 planes [2][Npad][ld] (hi, lo); lo plane at +lo_off ushorts
+    long long lo_off = 0;
 };
 
 class WeightStore {
@@ -193,7 +201,9 @@ public:
     explicit WeightStore(bool nk_layout = false) : nk_(nk_layout) {}
     ~WeightStore();
     // upload a host [K][Npad] matrix in this store's layout and fill w / ld / nk
-    void finish(PackedW& pw, const std::vector<float>& kn);
+    // bf16_ok: every use of this weight is eligible for the bf16 engine (then it is stored pre-split)
+    void finish(PackedW& pw, const std::vector<float>& kn, bool bf16_ok = false);
+    void* upload_raw(const void* host, size_t bytes);
     float* upload(const std::vector<float>& host);
     // conv / linear weight [Cout][Cin][KH][KW] (linear: KH=KW=1) -> [ (ky,kx,ci) ][Cout pad 32]
     PackedW pack_conv(const StateDict& sd, const std::string& wname, const std::string& bname, int KH, int KW);

@@ -30,12 +30,35 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return t;
 }
 
-// one block per (sample, group); threads = (position lane, channel-in-group)
-__global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict__ x1, int ld1, int C1,
-                                                        const float* __restrict__ x2, int ld2, int C2, int HW,
-                                                        int groups, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float eps, int silu,
-                                                        float* __restrict__ out) {
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 f = {a, b};
+    bf16x2 h = __builtin_convertvector(f, bf16x2);
+    return __builtin_bit_cast(unsigned, h);
+}
+// write 4 consecutive channels either as fp32 or as the bf16 hi / lo planes read by the bf16 GEMM engine
+// (hi = bf16(v), lo = bf16(v - hi); planes are `plane` ushort elements apart)
+__device__ __forceinline__ void store4(float* out, long long idx, long long plane, int split, float4 v) {
+    if (!split) {
+        *reinterpret_cast<float4*>(out + idx) = v;
+        return;
+    }
+    unsigned short* o = reinterpret_cast<unsigned short*>(out);
+    uint2 hi, lo;
+    hi.x = pk_bf16(v.x, v.y);
+    hi.y = pk_bf16(v.z, v.w);
+    lo.x = pk_bf16(v.x - __builtin_bit_cast(float, hi.x << 16), v.y - __builtin_bit_cast(float, hi.x & 0xffff0000u));
+    lo.y = pk_bf16(v.z - __builtin_bit_cast(float, hi.y << 16), v.w - __builtin_bit_cast(float, hi.y & 0xffff0000u));
+    *reinterpret_cast<uint2*>(o + idx) = hi;
+    *reinterpret_cast<uint2*>(o + plane + idx) = lo;
+}
+
+// GroupNorm pass 1: one block per (sample, group) -> stats[(b*groups+g)*2] = {mean, rstd}; threads = (position
+// lane, channel-in-group); mean first, then the centred second moment (as accurate as ATen's)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x1, int ld1, int C1,
+                                                       const float* __restrict__ x2, int ld2, int C2, int HW,
+                                                       int groups, float eps, float* __restrict__ stats) {
     __shared__ float red[4];
     const int C = C1 + C2, cpg = C / groups;
     const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
@@ -64,50 +87,89 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(const float* __restrict_
             q += d * d;
         }
     const float var = block_sum(q, red) / n;
-    const float rstd = 1.f / sqrtf(var + eps);
-    if (active) {
-        const float ga = gamma[c] * rstd, be = beta[c] - mean * rstd * gamma[c];
-        float* dst = out + (long long)b * HW * C + c;
-        for (int pos = tp; pos < HW; pos += tp_n) {
-            float v = src[pos * ld] * ga + be;
-            if (silu) v = v / (1.f + expf(-v));
-            dst[(long long)pos * C] = v;
-        }
+    if (threadIdx.x == 0) {
+        stats[2 * blockIdx.x] = mean;
+        stats[2 * blockIdx.x + 1] = 1.f / sqrtf(var + eps);
     }
 }
 
-// one wave per row, row cached in registers (C <= 64*NR)
+// GroupNorm pass 2: y = x*scale + shift (scale = gamma*rstd, shift = beta - mean*scale, as ATen) [+ SiLU], four
+// channels per thread, coalesced float4 in, fp32 or bf16-plane out
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x1, int ld1, int C1,
+                                                       const float* __restrict__ x2, int ld2, int C2, long long rows,
+                                                       int HW, int groups, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ stats,
+                                                       int silu, float* __restrict__ out, int split) {
+    const int C = C1 + C2, cpg = C / groups, c4n = C / 4;
+    const long long total = rows * c4n, plane = rows * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / c4n;
+        const int c = (int)(i - row * c4n) * 4;
+        const int b = (int)(row / HW);
+        const float4 v = c < C1 ? *reinterpret_cast<const float4*>(x1 + row * ld1 + c)
+                                : *reinterpret_cast<const float4*>(x2 + row * ld2 + (c - C1));
+        const float in[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ce = c + e;
+            const float* st = stats + 2 * (b * groups + ce / cpg);
+            const float sc = gamma[ce] * st[1];
+            float y = in[e] * sc + (beta[ce] - st[0] * sc);
+            if (silu) y = y / (1.f + expf(-y));
+            o[e] = y;
+        }
+        store4(out, row * C + c, plane, split, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+// LayerNorm: one wave per row, four channels per lane per step, row cached in registers (C <= 256*NR)
 template <int NR>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int rows, int C,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long rows, int C,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int split) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* src = x + (long long)row * C;
-    float v[NR];
+    const float* src = x + row * C;
+    float4 v[NR];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = c < C ? src[c] : 0.f;
-        s += v[i];
+        const int c = (lane + 64 * i) * 4;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) t = *reinterpret_cast<const float4*>(src + c);
+        v[i].x = t.x;
+        v[i].y = t.y;
+        v[i].z = t.z;
+        v[i].w = t.w;
+        s += (t.x + t.y) + (t.z + t.w);
     }
     const float mean = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const int c = lane + 64 * i;
-        const float d = c < C ? v[i] - mean : 0.f;
-        q += d * d;
+        const int c = (lane + 64 * i) * 4;
+        if (c < C) {
+            const float a = v[i].x - mean, b = v[i].y - mean, d = v[i].z - mean, e = v[i].w - mean;
+            q += (a * a + b * b) + (d * d + e * e);
+        }
     }
     const float rstd = 1.f / sqrtf(wave_sum(q) / (float)C + eps);
-    float* dst = out + (long long)row * C;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-        const int c = lane + 64 * i;
-        if (c < C) dst[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        const int c = (lane + 64 * i) * 4;
+        if (c < C) {
+            const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+            const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+            float4 y;
+            y.x = (v[i].x - mean) * rstd * g.x + bt.x;
+            y.y = (v[i].y - mean) * rstd * g.y + bt.y;
+            y.z = (v[i].z - mean) * rstd * g.z + bt.z;
+            y.w = (v[i].w - mean) * rstd * g.w + bt.w;
+            store4(out, row * C + c, rows * C, split, y);
+        }
     }
 }
 
@@ -158,29 +220,37 @@ __global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ s, lon
 
 }  // namespace
 
-void launch_groupnorm(const Ctx& ctx, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int B,
-                      int HW, int groups, const float* gamma, const float* beta, float eps, int silu, float* out) {
-    if (ctx.ws.dry) return;
+void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int B, int HW,
+                      int groups, const float* gamma, const float* beta, float eps, int silu, float* out,
+                      int out_split) {
     const int C = C1 + C2;
-    MAA_CHECK(C % groups == 0 && C / groups <= 256, "groupnorm channels");
+    float* stats = ctx.ws.alloc_f((size_t)2 * B * groups);    // released with the caller's arena mark
+    if (ctx.ws.dry) return;
+    MAA_CHECK(C % groups == 0 && C / groups <= 256 && C % 4 == 0 && C1 % 4 == 0 && ld1 % 4 == 0 && (C2 == 0 || ld2 % 4 == 0),
+              "groupnorm channels");
     ProfScope prof(ctx, "groupnorm", 0.0, 8.0 * B * (double)HW * C);
-    hipLaunchKernelGGL(groupnorm_kernel, dim3(B * groups), dim3(256), 0, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW,
-                       groups, gamma, beta, eps, silu, out);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW, groups,
+                       eps, stats);
+    const long long rows = (long long)B * HW, total = rows * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx.stream, x1, ld1, C1, x2, ld2, C2, rows,
+                       HW, groups, gamma, beta, stats, silu, out, out_split);
     MAA_HIP(hipGetLastError());
 }
 
-void launch_layernorm(const Ctx& ctx, const float* x, int rows, int C, const float* gamma, const float* beta,
-                      float eps, float* out) {
+void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, const float* gamma, const float* beta,
+                      float eps, float* out, int out_split) {
     if (ctx.ws.dry) return;
-    MAA_CHECK(C <= 1024, "layernorm width");
+    MAA_CHECK(C <= 1024 && C % 4 == 0, "layernorm width");
     ProfScope prof(ctx, "layernorm", 0.0, 8.0 * rows * (double)C);
-    dim3 grid((rows + 3) / 4);
-    if (C <= 320)
-        hipLaunchKernelGGL(layernorm_kernel<5>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out);
-    else if (C <= 640)
-        hipLaunchKernelGGL(layernorm_kernel<10>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out);
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (C <= 256)
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
+    else if (C <= 512)
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
     else
-        hipLaunchKernelGGL(layernorm_kernel<16>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out);
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
     MAA_HIP(hipGetLastError());
 }
 

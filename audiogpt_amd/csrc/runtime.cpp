@@ -149,7 +149,47 @@ float* WeightStore::vec(const StateDict& sd, const std::string& name) {
 
 static int pad32(int n) { return (n + 31) / 32 * 32; }
 
-void WeightStore::finish(PackedW& pw, const std::vector<float>& kn) {
+static inline unsigned short f2bf(float f) {      // round to nearest even, as v_cvt_pk_bf16_f32
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+static inline float bf2f(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+void* WeightStore::upload_raw(const void* host, size_t bytes) {
+    void* d = nullptr;
+    MAA_HIP(hipMalloc(&d, bytes ? bytes : 4));
+    if (bytes) MAA_HIP(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+    bufs_.push_back(d);
+    bytes_ += bytes;
+    return d;
+}
+
+void WeightStore::finish(PackedW& pw, const std::vector<float>& kn, bool bf16_ok) {
+    if (nk_ && bf16_ok) {
+        // pre-split planes [2][Npad][K8]: hi = bf16(w), lo = bf16(w - hi); the kernel copies them straight to LDS
+        const int K8 = (pw.K + 7) / 8 * 8;
+        const size_t plane = (size_t)pw.Npad * K8;
+        std::vector<unsigned short> t(2 * plane, 0);
+        for (int k = 0; k < pw.K; ++k)
+            for (int n = 0; n < pw.Npad; ++n) {
+                const float w = kn[(size_t)k * pw.Npad + n];
+                const unsigned short hi = f2bf(w);
+                t[(size_t)n * K8 + k] = hi;
+                t[plane + (size_t)n * K8 + k] = f2bf(w - bf2f(hi));
+            }
+        pw.w = static_cast<float*>(upload_raw(t.data(), t.size() * sizeof(unsigned short)));
+        pw.ld = K8;
+        pw.nk = 1;
+        pw.split = 1;
+        pw.lo_off = (long long)plane;
+        return;
+    }
     if (!nk_) {
         pw.w = upload(kn);
         pw.ld = pw.Npad;
@@ -180,7 +220,7 @@ PackedW WeightStore::pack_conv(const StateDict& sd, const std::string& wname, co
         for (int ci = 0; ci < Cin; ++ci)
             for (int t = 0; t < KH * KW; ++t)
                 h[((size_t)t * Cin + ci) * pw.Npad + co] = w.data[((size_t)co * Cin + ci) * KH * KW + t];
-    finish(pw, h);
+    finish(pw, h, KH * KW == 1 ? Cin % 8 == 0 : Cin % 32 == 0);
     if (!bname.empty()) {
         const HostTensor& b = get(sd, bname);
         std::vector<float> hb(pw.Npad, 0.f);
@@ -217,7 +257,7 @@ PackedW WeightStore::pack_concat(const StateDict& sd, const std::vector<std::str
         }
         col += co_n;
     }
-    finish(pw, h);
+    finish(pw, h, Cin % 8 == 0);
     bool any_bias = false;
     for (auto& b : bnames) any_bias = any_bias || !b.empty();
     if (any_bias) pw.bias = upload(hb);
@@ -247,7 +287,7 @@ PackedW WeightStore::pack_geglu(const StateDict& sd, const std::string& wname, c
         hb[cv] = b.data[j];
         hb[cg] = b.data[inner + j];
     }
-    finish(pw, h);
+    finish(pw, h, Cin % 8 == 0);
     pw.bias = upload(hb);
     return pw;
 }
@@ -285,7 +325,7 @@ PackedW WeightStore::pack_convtr_phase(const StateDict& sd, const std::string& w
         }
         for (int co = 0; co < Cout; ++co) hb[ri * Cout + co] = b.data[co];
     }
-    finish(pw, h);
+    finish(pw, h, Cin % 32 == 0);
     pw.bias = upload(hb);
     return pw;
 }

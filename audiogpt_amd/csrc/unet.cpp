@@ -249,8 +249,9 @@ struct UNet::Impl {
         T4 out = alloc_t(ctx, B, Ho, Wo, r.cout);
         const size_t mk = ctx.ws.mark();
         T4 t1 = alloc_t(ctx, B, H, W, r.cin);
+        t1.split = r.updown != 1 && split_for_gemm(ctx, r.cin);     // (the avg-pool of a down block reads fp32)
         launch_groupnorm(ctx, x1.p, x1.C, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x2 ? x2->C : 0, B, H * W, 32,
-                         r.g1, r.b1, 1e-5f, 1, t1.p);
+                         r.g1, r.b1, 1e-5f, 1, t1.p, t1.split);
         T4 h1 = alloc_t(ctx, B, Ho, Wo, r.cout);
         ConvOpt o1;
         o1.KH = o1.KW = 3;
@@ -277,7 +278,8 @@ struct UNet::Impl {
             resid = x1.p;
         }
         T4 t2 = alloc_t(ctx, B, Ho, Wo, r.cout);
-        launch_groupnorm(ctx, h1.p, r.cout, r.cout, nullptr, 0, 0, B, Ho * Wo, 32, r.g2, r.b2, 1e-5f, 1, t2.p);
+        t2.split = split_for_gemm(ctx, r.cout);
+        launch_groupnorm(ctx, h1.p, r.cout, r.cout, nullptr, 0, 0, B, Ho * Wo, 32, r.g2, r.b2, 1e-5f, 1, t2.p, t2.split);
         if (r.has_skip) {
             MAA_CHECK(r.updown == 0, "skip conv with up/down");
             T4 sk = alloc_t(ctx, B, H, W, r.cout);
@@ -302,25 +304,26 @@ struct UNet::Impl {
         T4 out = alloc_t(ctx, B, x.H, x.W, s.ch);
         const size_t mk = ctx.ws.mark();
         float* xn = ctx.ws.alloc_f((size_t)M * s.ch);
-        launch_groupnorm(ctx, x.p, s.ch, s.ch, nullptr, 0, 0, B, HW, 32, s.ng, s.nb, 1e-6f, 0, xn);
+        const bool sp_in = split_for_gemm(ctx, s.ch), sp = split_for_gemm(ctx, inner);
+        launch_groupnorm(ctx, x.p, s.ch, s.ch, nullptr, 0, 0, B, HW, 32, s.ng, s.nb, 1e-6f, 0, xn, sp_in);
         float* y = ctx.ws.alloc_f((size_t)M * inner);
-        linear_into(ctx, xn, s.ch, M, s.ch, s.proj_in, nullptr, 0, y, inner);
+        linear_into(ctx, xn, s.ch, M, s.ch, s.proj_in, nullptr, 0, y, inner, 0, 0, sp_in ? M : 0);
         const float scale = 1.0f / std::sqrt((float)s.dh);
         for (const STBlockW& b : s.blocks) {
             float* ln = ctx.ws.alloc_f((size_t)M * inner);
             float* o = ctx.ws.alloc_f((size_t)M * inner);
             // x = attn1(norm1(x)) + x      (attention.py:212)
-            launch_layernorm(ctx, y, (int)M, inner, b.ln1g, b.ln1b, 1e-5f, ln);
+            launch_layernorm(ctx, y, M, inner, b.ln1g, b.ln1b, 1e-5f, ln, sp);
             float* qkv = ctx.ws.alloc_f((size_t)M * 3 * inner);
-            linear_into(ctx, ln, inner, M, inner, b.qkv1, nullptr, 0, qkv, 3 * inner);
+            linear_into(ctx, ln, inner, M, inner, b.qkv1, nullptr, 0, qkv, 3 * inner, 0, 0, sp ? M : 0);
             attention_into(ctx, qkv, 3 * inner, s.dh, qkv + inner, 3 * inner, s.dh, qkv + 2 * inner, 3 * inner, s.dh,
                            B, s.heads, s.dh, HW, HW, scale, o, inner);
             float* y1 = ctx.ws.alloc_f((size_t)M * inner);
             linear_into(ctx, o, inner, M, inner, b.out1, y, inner, y1, inner);
             // x = attn2(norm2(x), context) + x      (:213)
-            launch_layernorm(ctx, y1, (int)M, inner, b.ln2g, b.ln2b, 1e-5f, ln);
+            launch_layernorm(ctx, y1, M, inner, b.ln2g, b.ln2b, 1e-5f, ln, sp);
             float* q = ctx.ws.alloc_f((size_t)M * inner);
-            linear_into(ctx, ln, inner, M, inner, b.q2, nullptr, 0, q, inner);
+            linear_into(ctx, ln, inner, M, inner, b.q2, nullptr, 0, q, inner, 0, 0, sp ? M : 0);
             MAA_CHECK(ctx.ws.dry || (kv_cache[b.kv_slot] && kv_batch == B), "set_context must precede forward (batch)");
             const float* kv = kv_cache[b.kv_slot];
             attention_into(ctx, q, inner, s.dh, kv, 2 * inner, s.dh, kv + inner, 2 * inner, s.dh, B, s.heads, s.dh, HW,
@@ -328,9 +331,9 @@ struct UNet::Impl {
             float* y2 = ctx.ws.alloc_f((size_t)M * inner);
             linear_into(ctx, o, inner, M, inner, b.out2, y1, inner, y2, inner);
             // x = ff(norm3(x)) + x      (:214)
-            launch_layernorm(ctx, y2, (int)M, inner, b.ln3g, b.ln3b, 1e-5f, ln);
+            launch_layernorm(ctx, y2, M, inner, b.ln3g, b.ln3b, 1e-5f, ln, sp);
             float* g = ctx.ws.alloc_f((size_t)M * 4 * inner);
-            linear_into(ctx, ln, inner, M, inner, b.ff1, nullptr, 0, g, 4 * inner, /*geglu=*/1);
+            linear_into(ctx, ln, inner, M, inner, b.ff1, nullptr, 0, g, 4 * inner, /*geglu=*/1, 0, sp ? M : 0);
             float* y3 = ctx.ws.alloc_f((size_t)M * inner);
             linear_into(ctx, g, 4 * inner, M, 4 * inner, b.ff2, y2, inner, y3, inner);
             y = y3;
@@ -348,9 +351,10 @@ struct UNet::Impl {
         T4 out = alloc_t(ctx, B, x.H, x.W, C);
         const size_t mk = ctx.ws.mark();
         float* xn = ctx.ws.alloc_f((size_t)M * C);
-        launch_groupnorm(ctx, x.p, C, C, nullptr, 0, 0, B, HW, 32, a.ng, a.nb, 1e-5f, 0, xn);
+        const bool sp = split_for_gemm(ctx, C);
+        launch_groupnorm(ctx, x.p, C, C, nullptr, 0, 0, B, HW, 32, a.ng, a.nb, 1e-5f, 0, xn, sp);
         float* qkv = ctx.ws.alloc_f((size_t)M * 3 * C);
-        linear_into(ctx, xn, C, M, C, a.qkv, nullptr, 0, qkv, 3 * C);
+        linear_into(ctx, xn, C, M, C, a.qkv, nullptr, 0, qkv, 3 * C, 0, 0, sp ? M : 0);
         float* o = ctx.ws.alloc_f((size_t)M * C);
         const float sc = 1.0f / std::sqrt(std::sqrt((float)dh));
         attention_into(ctx, qkv, 3 * C, 3 * dh, qkv + dh, 3 * C, 3 * dh, qkv + 2 * dh, 3 * C, 3 * dh, B, a.heads, dh, HW,
@@ -441,7 +445,8 @@ struct UNet::Impl {
             h = run_layers(ctx, blk, h, &skip, emb_out);
         }
         T4 hn = alloc_t(ctx, B, H, W, mc);
-        launch_groupnorm(ctx, h.p, mc, mc, nullptr, 0, 0, B, H * W, 32, out_g, out_b, 1e-5f, 1, hn.p);
+        hn.split = split_for_gemm(ctx, mc);
+        launch_groupnorm(ctx, h.p, mc, mc, nullptr, 0, 0, B, H * W, 32, out_g, out_b, 1e-5f, 1, hn.p, hn.split);
         T4 o = alloc_t(ctx, B, H, W, cfg.out_channels);
         ConvOpt co;
         co.KH = co.KW = 3;

@@ -156,14 +156,16 @@ struct VAE::Impl {
         T4 out = alloc_t(ctx, x.B, x.H, x.W, r.cout);
         const size_t mk = ctx.ws.mark();
         T4 t1 = alloc_t(ctx, x.B, x.H, x.W, r.cin);
-        launch_groupnorm(ctx, x.p, r.cin, r.cin, nullptr, 0, 0, x.B, x.H * x.W, 32, r.g1, r.b1, 1e-6f, 1, t1.p);
+        t1.split = split_for_gemm(ctx, r.cin);
+        launch_groupnorm(ctx, x.p, r.cin, r.cin, nullptr, 0, 0, x.B, x.H * x.W, 32, r.g1, r.b1, 1e-6f, 1, t1.p, t1.split);
         T4 h1 = alloc_t(ctx, x.B, x.H, x.W, r.cout);
         ConvOpt o;
         o.KH = o.KW = 3;
         o.pad = 1;
         conv_into(ctx, t1, nullptr, r.conv1, o, h1);
         T4 t2 = alloc_t(ctx, x.B, x.H, x.W, r.cout);
-        launch_groupnorm(ctx, h1.p, r.cout, r.cout, nullptr, 0, 0, x.B, x.H * x.W, 32, r.g2, r.b2, 1e-6f, 1, t2.p);
+        t2.split = split_for_gemm(ctx, r.cout);
+        launch_groupnorm(ctx, h1.p, r.cout, r.cout, nullptr, 0, 0, x.B, x.H * x.W, 32, r.g2, r.b2, 1e-6f, 1, t2.p, t2.split);
         const float* resid = x.p;
         if (r.has_nin) {
             T4 sk = alloc_t(ctx, x.B, x.H, x.W, r.cout);
@@ -184,9 +186,10 @@ struct VAE::Impl {
         T4 out = alloc_t(ctx, x.B, x.H, x.W, C);
         const size_t mk = ctx.ws.mark();
         float* xn = ctx.ws.alloc_f((size_t)M * C);
-        launch_groupnorm(ctx, x.p, C, C, nullptr, 0, 0, x.B, HW, 32, a.ng, a.nb, 1e-6f, 0, xn);
+        const bool sp = split_for_gemm(ctx, C);
+        launch_groupnorm(ctx, x.p, C, C, nullptr, 0, 0, x.B, HW, 32, a.ng, a.nb, 1e-6f, 0, xn, sp);
         float* qkv = ctx.ws.alloc_f((size_t)M * 3 * C);
-        linear_into(ctx, xn, C, M, C, a.qkv, nullptr, 0, qkv, 3 * C);
+        linear_into(ctx, xn, C, M, C, a.qkv, nullptr, 0, qkv, 3 * C, 0, 0, sp ? M : 0);
         float* o = ctx.ws.alloc_f((size_t)M * C);
         // w = softmax(q k^T * C^-1/2) over keys; h = w v   (model.py:186-198)
         const float sc = (float)std::pow((double)(int)C, -0.5);
@@ -227,8 +230,9 @@ struct VAE::Impl {
             }
         }
         T4 hn = alloc_t(ctx, B, hcur.H, hcur.W, d_last_c);
+        hn.split = split_for_gemm(ctx, d_last_c);
         launch_groupnorm(ctx, hcur.p, d_last_c, d_last_c, nullptr, 0, 0, B, hcur.H * hcur.W, 32, d_ng, d_nb, 1e-6f, 1,
-                         hn.p);
+                         hn.p, hn.split);
         T4 out = alloc_t(ctx, B, hcur.H, hcur.W, cfg.out_ch);
         conv_into(ctx, hn, nullptr, d_conv_out, o3, out);
         launch_nhwc_to_nchw(ctx, out.p, B, cfg.out_ch, hcur.H * hcur.W, mel_nchw, cfg.out_ch);
@@ -266,7 +270,9 @@ struct VAE::Impl {
         hcur = run_attn(ctx, e_mid_attn, hcur);
         hcur = run_res(ctx, e_mid2, hcur);
         T4 hn = alloc_t(ctx, B, hcur.H, hcur.W, hcur.C);
-        launch_groupnorm(ctx, hcur.p, hcur.C, hcur.C, nullptr, 0, 0, B, hcur.H * hcur.W, 32, e_ng, e_nb, 1e-6f, 1, hn.p);
+        hn.split = split_for_gemm(ctx, hcur.C);
+        launch_groupnorm(ctx, hcur.p, hcur.C, hcur.C, nullptr, 0, 0, B, hcur.H * hcur.W, 32, e_ng, e_nb, 1e-6f, 1, hn.p,
+                         hn.split);
         const int oc = (cfg.double_z ? 2 : 1) * cfg.z_channels;
         T4 eo = alloc_t(ctx, B, hcur.H, hcur.W, oc);
         conv_into(ctx, hn, nullptr, e_conv_out, o3, eo);
