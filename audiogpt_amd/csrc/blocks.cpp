@@ -88,6 +88,7 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
 
 void attention_into(Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk, const float* v,
                     int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha, float* out, int ldo) {
+    if (launch_flash_attention(ctx, q, ldq, hsq, k, ldk, hsk, v, ldv, hsv, B, heads, dh, Nq, Nk, alpha, out, ldo)) return;
     const size_t mk = ctx.ws.mark();
     const int ldS = (Nk + 3) / 4 * 4;
     float* S = ctx.ws.alloc_f((size_t)B * heads * Nq * ldS);

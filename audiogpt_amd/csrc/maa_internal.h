@@ -149,6 +149,10 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
                       int out_split = 0);
 void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, const float* gamma, const float* beta,
                       float eps, float* out, int out_split = 0);
+// fused softmax(alpha q k^T) v for the bf16 precision modes; false = shape not covered, use the GEMM path
+bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
+                            const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,
+                            float* out, int ldo);
 // in-place row softmax over `cols` columns of a [rows, ld] matrix; columns [cols, ld) are zeroed
 void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld);
 

@@ -90,7 +90,9 @@ def test_conv_transpose1d(ctx):
     check(f"{ctx.precision}_convtr", y, ref, TOL[ctx.precision])
 
 
-@pytest.mark.parametrize("B,heads,dh,Nq,Nk", [(2, 8, 40, 780, 780), (2, 8, 40, 780, 77), (1, 1, 512, 780, 780)])
+@pytest.mark.parametrize("B,heads,dh,Nq,Nk", [(2, 8, 40, 780, 780), (2, 8, 40, 780, 77), (1, 1, 512, 780, 780),
+                                              (2, 8, 80, 195, 195), (2, 8, 80, 195, 77), (3, 16, 32, 195, 1),
+                                              (1, 8, 40, 1060, 1060), (2, 4, 64, 130, 33), (1, 8, 80, 265, 265)])
 def test_attention(ctx, B, heads, dh, Nq, Nk):
     Cc = heads * dh
     q = torch.randn(B, Nq, Cc, generator=g(34))
