@@ -64,7 +64,15 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // [buf][plane][row][LDK]
 
     const int tid = threadIdx.x;
-    const int bid = blockIdx.x;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own 4 MB L2), so consecutive TILES are
+    // handed to the SAME XCD -- the N-tiles of one M-tile and the neighbouring M-tiles (which share A rows through
+    // the conv halo) then hit in one L2 instead of being fetched over the fabric once per XCD.  Bijective for any
+    // grid size; a pure speed choice, results do not depend on placement.
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    }
     const int nt = bid % ntiles, mt = bid / ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int z = blockIdx.y;
