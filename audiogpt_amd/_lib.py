@@ -65,7 +65,7 @@ EXPORTS = [
     "maa_unet_set_context", "maa_unet_forward", "maa_ddim_update", "maa_ddim_sample", "maa_vae_create",
     "maa_vae_destroy", "maa_vae_decode", "maa_vae_encode_moments", "maa_vocoder_create", "maa_vocoder_destroy",
     "maa_vocoder_forward", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
-    "maa_op_attention", "maa_op_conv_transpose1d", "maa_op_snake_aa",
+    "maa_op_attention", "maa_op_conv_transpose1d", "maa_op_snake_aa", "maa_op_bench_conv",
 ]
 
 _lib = None
@@ -114,6 +114,7 @@ def load():
         "maa_op_attention": [vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, vp],
         "maa_op_conv_transpose1d": [vp, vp, ci, ci, ci, fp, fp, ci, ci, ci, cf, vp],
         "maa_op_snake_aa": [vp, vp, ci, ci, ci, fp, fp, ci, vp],
+        "maa_op_bench_conv": [vp, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_float)],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)

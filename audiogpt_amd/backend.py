@@ -146,6 +146,12 @@ class Context:
                                                  L.dptr(y)))
         return y
 
+    def op_bench_conv(self, B, H, W, Cin, Cout, taps=9, pre_split=True, iters=20):
+        """Kernel-only time (ms per launch) of one conv in this context's precision mode, synthetic data."""
+        ms = C.c_float()
+        L.check(self.lib.maa_op_bench_conv(self.h, B, H, W, Cin, Cout, taps, int(pre_split), iters, C.byref(ms)))
+        return ms.value
+
     def op_snake_aa(self, x, alpha, beta, logscale):
         x = _f32(x, self.device)
         B, Cc, Ln = x.shape

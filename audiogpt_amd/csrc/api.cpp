@@ -443,6 +443,64 @@ int maa_op_conv_transpose1d(maa_ctx* ctx, const float* d_x, int B, int Cin, int 
     });
 }
 
+int maa_op_bench_conv(maa_ctx* ctx, int B, int H, int W, int Cin, int Cout, int taps, int pre_split, int iters,
+                      float* ms_per_launch) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(ms_per_launch && iters > 0 && (taps == 1 || taps == 9), "bad op_bench_conv arguments");
+        maa::Ctx& c = ctx->c;
+        const int k = taps == 9 ? 3 : 1;
+        std::vector<float> hw((size_t)Cout * Cin * taps), hb(Cout, 0.1f);
+        unsigned s = 12345u;
+        for (auto& v : hw) {
+            s = s * 1664525u + 1013904223u;
+            v = ((int)(s >> 9) % 2001 - 1000) * 1e-4f;
+        }
+        OneShot sd;
+        sd.add("w", hw.data(), {Cout, Cin, k, k});
+        sd.add("b", hb.data(), {Cout});
+        maa::WeightStore ws(c.dtype != 0);
+        maa::PackedW pw = ws.pack_conv(sd.sd, "w", "b", k, k);
+        const size_t n_in = (size_t)B * H * W * Cin, n_out = (size_t)B * H * W * Cout;
+        std::vector<float> hx(n_in);
+        for (auto& v : hx) {
+            s = s * 1664525u + 1013904223u;
+            v = ((int)(s >> 9) % 2001 - 1000) * 1e-3f;
+        }
+        float* dx = ws.upload(hx);
+        float* dy = ws.upload(std::vector<float>(n_out, 0.f));
+        maa::T4 x, y;
+        x.B = y.B = B;
+        x.H = y.H = H;
+        x.W = y.W = W;
+        x.C = Cin;
+        y.C = Cout;
+        x.p = dx;
+        y.p = dy;
+        if (pre_split && c.dtype != 0) {
+            // reinterpret the same bytes as bf16 planes: arbitrary but finite bf16 values (both fp32 halves are
+            // valid bf16 bit patterns of small numbers), enough for timing
+            x.split = true;
+        }
+        maa::ConvOpt o;
+        o.KH = o.KW = k;
+        o.pad = k / 2;
+        for (int i = 0; i < 3; ++i) maa::conv_into(c, x, nullptr, pw, o, y);
+        hipEvent_t e0, e1;
+        MAA_HIP(hipEventCreate(&e0));
+        MAA_HIP(hipEventCreate(&e1));
+        MAA_HIP(hipEventRecord(e0, c.stream));
+        for (int i = 0; i < iters; ++i) maa::conv_into(c, x, nullptr, pw, o, y);
+        MAA_HIP(hipEventRecord(e1, c.stream));
+        MAA_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        MAA_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *ms_per_launch = ms / iters;
+    });
+}
+
 int maa_op_snake_aa(maa_ctx* ctx, const float* d_x, int B, int C, int L, const float* h_alpha, const float* h_beta,
                     int logscale, float* d_y) {
     return guarded([&] {

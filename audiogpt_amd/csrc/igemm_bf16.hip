@@ -13,6 +13,8 @@
 // ds_read_b128.  B must be given k-contiguous ([N][K]: packed weights in this mode, and K of Q.K^T).
 #include "igemm_epilogue.h"
 
+#include <cstdlib>
+
 namespace maa {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -21,8 +23,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int BK = 32;
-constexpr int LDK = 40;      // bf16 elements per LDS row (32 + 8 pad)
 constexpr int NT = 256;
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
@@ -48,16 +48,26 @@ __device__ __forceinline__ void st16(unsigned short* dst, const float4& v) {   /
     *reinterpret_cast<f32x4*>(dst) = t;
 }
 
-template <int BM, int BN, int WGM, int WGN, int TERMS, bool A_SPLIT, bool B_SPLIT>
+// BK: K depth of one LDS stage (32 or 64); NBUF: LDS stages (2 = one barrier per chunk, 1 = half the LDS and two
+// barriers per chunk, which admits twice the workgroups per CU)
+template <int BM, int BN, int WGM, int WGN, int TERMS, bool A_SPLIT, bool B_SPLIT, int BK, int NBUF>
 __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntiles, int Nb) {
+    // LDS rows are 64 B (32 bf16) with NO padding; the 16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3).
+    // That XOR swizzle makes both the ds_write_b128 of the staging pass (8-lane groups = two rows = 32 distinct
+    // banks) and the ds_read_b128 of the MFMA operands (16-lane groups {0-3,12-15,20-27} -> 16 distinct 16-byte
+    // slots) conflict-free, and saves the 25 % of LDS a padded pitch costs.
+    static_assert(BK == 32, "swizzle is written for 4 chunks per row");
+    constexpr int LDK = BK;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
     constexpr int PLANES = TERMS == 1 ? 1 : 2;
     constexpr int ROWS = BM + BN;
     constexpr int PLANE_ELEMS = ROWS * LDK;            // bf16 elements of one plane of one buffer
     // per-thread 16-byte loads per chunk: fp32 operand: rows/32 float4; split operand: (rows/64 row slots) x planes
-    constexpr int ARS = A_SPLIT ? (BM >= 64 ? BM / 64 : 1) : BM / 32;       // row slots of this thread
-    constexpr int BRS = B_SPLIT ? (BN >= 64 ? BN / 64 : 1) : BN / 32;
+    constexpr int TPR_S = BK / 8, RPP_S = NT / TPR_S;  // split operand: threads per row (16 B each), rows per pass
+    constexpr int TPR_F = BK / 4, RPP_F = NT / TPR_F;  // fp32 operand: threads per row (float4 each), rows per pass
+    constexpr int ARS = A_SPLIT ? (BM >= RPP_S ? BM / RPP_S : 1) : (BM >= RPP_F ? BM / RPP_F : 1);   // row slots
+    constexpr int BRS = B_SPLIT ? (BN >= RPP_S ? BN / RPP_S : 1) : (BN >= RPP_F ? BN / RPP_F : 1);
     constexpr int AL = A_SPLIT ? ARS * PLANES : ARS;
     constexpr int BL = B_SPLIT ? BRS * PLANES : BRS;
     static_assert(WGM * WGN == 4 && BM % 32 == 0 && BN % 32 == 0, "tile");
@@ -92,10 +102,10 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     const float slope = p.a_act == 1 ? p.a_slope : 1.0f;
 
     // thread -> (row slot, k offset) for each operand form
-    const int a_r0 = A_SPLIT ? (tid >> 2) : (tid >> 3), a_rstep = A_SPLIT ? 64 : 32;
-    const int a_k = A_SPLIT ? (tid & 3) * 8 : (tid & 7) * 4;
-    const int b_r0 = B_SPLIT ? (tid >> 2) : (tid >> 3), b_rstep = B_SPLIT ? 64 : 32;
-    const int b_k = B_SPLIT ? (tid & 3) * 8 : (tid & 7) * 4;
+    const int a_r0 = A_SPLIT ? tid / TPR_S : tid / TPR_F, a_rstep = A_SPLIT ? RPP_S : RPP_F;
+    const int a_k = A_SPLIT ? (tid % TPR_S) * 8 : (tid % TPR_F) * 4;
+    const int b_r0 = B_SPLIT ? tid / TPR_S : tid / TPR_F, b_rstep = B_SPLIT ? RPP_S : RPP_F;
+    const int b_k = B_SPLIT ? (tid % TPR_S) * 8 : (tid % TPR_F) * 4;
 
     // ---- A rows of this thread
     int a_b[ARS], a_iy0[ARS], a_ix0[ARS];
@@ -224,8 +234,8 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
             for (int q = 0; q < AL; ++q) {
                 const int pl = q / ARS, j = q % ARS;
                 const int row = a_r0 + a_rstep * j;
-                if (BM >= 64 || row < BM)
-                    st16(base + pl * PLANE_ELEMS + row * LDK + a_k, ra[q]);
+                if (BM >= RPP_S || row < BM)
+                    st16(base + pl * PLANE_ELEMS + row * LDK + (((a_k >> 3) ^ ((row >> 2) & 3)) << 3), ra[q]);
             }
         } else {
 #pragma unroll
@@ -235,7 +245,9 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
                 v.y = fmaxf(v.y, v.y * slope);
                 v.z = fmaxf(v.z, v.z * slope);
                 v.w = fmaxf(v.w, v.w * slope);
-                put_f32(base, (a_r0 + a_rstep * j) * LDK + a_k, v);
+                const int row = a_r0 + a_rstep * j;
+                if (BM >= RPP_F || row < BM)
+                    put_f32(base, row * LDK + (((a_k >> 3) ^ ((row >> 2) & 3)) << 3) + (a_k & 7), v);
             }
         }
         if constexpr (B_SPLIT) {
@@ -243,12 +255,16 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
             for (int q = 0; q < BL; ++q) {
                 const int pl = q / BRS, j = q % BRS;
                 const int row = b_r0 + b_rstep * j;
-                if (BN >= 64 || row < BN)
-                    st16(base + pl * PLANE_ELEMS + (BM + row) * LDK + b_k, rb[q]);
+                if (BN >= RPP_S || row < BN)
+                    st16(base + pl * PLANE_ELEMS + (BM + row) * LDK + (((b_k >> 3) ^ ((row >> 2) & 3)) << 3), rb[q]);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < BRS; ++j) put_f32(base, (BM + b_r0 + b_rstep * j) * LDK + b_k, rb[j]);
+            for (int j = 0; j < BRS; ++j) {
+                const int row = b_r0 + b_rstep * j;
+                if (BN >= RPP_F || row < BN)
+                    put_f32(base, (BM + row) * LDK + (((b_k >> 3) ^ ((row >> 2) & 3)) << 3) + (b_k & 7), rb[j]);
+            }
         }
     };
 
@@ -263,34 +279,44 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WGN, wn = wid - wm * WGN;
     const int lrow = lane & 31, lk = lane >> 5;
-    const int a_off = (wm * WTM + lrow) * LDK + lk * 8;
-    const int b_off = (BM + wn * WTN + lrow) * LDK + lk * 8;
+    const int a_row = (wm * WTM + lrow) * LDK, b_row = (BM + wn * WTN + lrow) * LDK;
+    const int sw = (lrow >> 2) & 3;          // row swizzle of this lane's rows (tile offsets are multiples of 32)
 
     auto compute = [&](int buf) {
         const unsigned short* base = smem + buf * PLANES * PLANE_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+            const int ch = ((ks * 2 + lk) ^ sw) << 3;
             bf16x8 ah[MI], bh[NI], al[MI], bl[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(base + a_off + i * 32 * LDK + ks * 16);
-                if constexpr (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(base + PLANE_ELEMS + a_off + i * 32 * LDK + ks * 16);
+                ah[i] = *reinterpret_cast<const bf16x8*>(base + a_row + i * 32 * LDK + ch);
+                if constexpr (TERMS == 3) al[i] = *reinterpret_cast<const bf16x8*>(base + PLANE_ELEMS + a_row + i * 32 * LDK + ch);
             }
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(base + b_off + j * 32 * LDK + ks * 16);
-                if constexpr (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(base + PLANE_ELEMS + b_off + j * 32 * LDK + ks * 16);
+                bh[j] = *reinterpret_cast<const bf16x8*>(base + b_row + j * 32 * LDK + ch);
+                if constexpr (TERMS == 3) bl[j] = *reinterpret_cast<const bf16x8*>(base + PLANE_ELEMS + b_row + j * 32 * LDK + ch);
+            }
+            // term-major order: the three products of one accumulator are separated by the other accumulators'
+            // MFMAs (same per-accumulator order lo.hi, hi.lo, hi.hi, so results do not depend on the tile shape)
+            if constexpr (TERMS == 3) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    if constexpr (TERMS == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
         }
     };
 
@@ -302,32 +328,49 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     load_b(rb0, 0);
     load_a(ra1);
     load_b(rb1, BK);
-    store_tiles(ra0, rb0, 0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; c += 2) {
-        load_a(ra0);
-        load_b(rb0, (c + 2) * BK);
-        compute(0);
-        store_tiles(ra1, rb1, 1);
-        __syncthreads();
-        load_a(ra1);
-        load_b(rb1, (c + 3) * BK);
-        compute(1);
+    if constexpr (NBUF == 2) {
         store_tiles(ra0, rb0, 0);
         __syncthreads();
+        for (int c = 0; c < nchunks; c += 2) {
+            load_a(ra0);
+            load_b(rb0, (c + 2) * BK);
+            compute(0);
+            store_tiles(ra1, rb1, 1);
+            __syncthreads();
+            load_a(ra1);
+            load_b(rb1, (c + 3) * BK);
+            compute(1);
+            store_tiles(ra0, rb0, 0);
+            __syncthreads();
+        }
+    } else {
+        for (int c = 0; c < nchunks; c += 2) {
+            __syncthreads();                 // every wave is done reading the stage
+            store_tiles(ra0, rb0, 0);
+            __syncthreads();
+            load_a(ra0);
+            load_b(rb0, (c + 2) * BK);
+            compute(0);
+            __syncthreads();
+            store_tiles(ra1, rb1, 0);
+            __syncthreads();
+            load_a(ra1);
+            load_b(rb1, (c + 3) * BK);
+            compute(0);
+        }
     }
 
     igemm_epilogue<MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lrow, lk, coff, Nb, rpb);
 }
 
-template <int BM, int BN, int WGM, int WGN, int TERMS, bool AS, bool BS>
+template <int BM, int BN, int WGM, int WGN, int TERMS, bool AS, bool BS, int BKT, int NBUF>
 void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
     const int ncols = p.N * (p.geglu ? 2 : 1);
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (ncols + BN - 1) / BN;
     dim3 grid((unsigned)((long long)mtiles * ntiles), (unsigned)p.Z);
     constexpr int planes = TERMS == 1 ? 1 : 2;
-    constexpr size_t lds = (size_t)2 * planes * (BM + BN) * LDK * sizeof(unsigned short);
-    auto kern = igemm_bf16_kernel<BM, BN, WGM, WGN, TERMS, AS, BS>;
+    constexpr size_t lds = (size_t)NBUF * planes * (BM + BN) * BKT * sizeof(unsigned short);
+    auto kern = igemm_bf16_kernel<BM, BN, WGM, WGN, TERMS, AS, BS, BKT, NBUF>;
     static bool attr_set = false;
     if (!attr_set) {
         MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -336,24 +379,29 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, p, ntiles, Nb);
 }
 
-template <int TERMS, bool AS, bool BS>
+template <int TERMS, bool AS, bool BS, int BKT, int NBUF>
 void launch_tile(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
     switch (cfg) {
-        case 0: launch_one<128, 128, 2, 2, TERMS, AS, BS>(ctx, p, Nb); break;
-        case 1: launch_one<128, 64, 2, 2, TERMS, AS, BS>(ctx, p, Nb); break;
-        case 2: launch_one<64, 64, 2, 2, TERMS, AS, BS>(ctx, p, Nb); break;
-        default: launch_one<256, 32, 4, 1, TERMS, AS, BS>(ctx, p, Nb); break;
+        case 0: launch_one<128, 128, 2, 2, TERMS, AS, BS, BKT, NBUF>(ctx, p, Nb); break;
+        case 1: launch_one<128, 64, 2, 2, TERMS, AS, BS, BKT, NBUF>(ctx, p, Nb); break;
+        case 2: launch_one<64, 64, 2, 2, TERMS, AS, BS, BKT, NBUF>(ctx, p, Nb); break;
+        default: launch_one<256, 32, 4, 1, TERMS, AS, BS, BKT, NBUF>(ctx, p, Nb); break;
     }
+}
+
+template <int TERMS, int BKT, int NBUF>
+void launch_split(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
+    if (p.a_split && p.b_split)
+        launch_tile<TERMS, true, true, BKT, NBUF>(ctx, p, cfg, Nb);
+    else if (p.b_split)
+        launch_tile<TERMS, false, true, BKT, NBUF>(ctx, p, cfg, Nb);
+    else
+        launch_tile<TERMS, false, false, BKT, NBUF>(ctx, p, cfg, Nb);
 }
 
 template <int TERMS>
 void launch_terms(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
-    if (p.a_split && p.b_split)
-        launch_tile<TERMS, true, true>(ctx, p, cfg, Nb);
-    else if (p.b_split)
-        launch_tile<TERMS, false, true>(ctx, p, cfg, Nb);
-    else
-        launch_tile<TERMS, false, false>(ctx, p, cfg, Nb);
+    launch_split<TERMS, 32, 2>(ctx, p, cfg, Nb);
 }
 
 }  // namespace
@@ -367,6 +415,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     }
     const int taps = p.KH * p.KW, Ctot = p.C1 + p.C2;
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    constexpr int BK = 32;      // channel granularity of the multi-tap gather (64-deep stages take two taps' worth)
     bool fast;
     if (p.a_split) {
         // bf16 planes: 8-element (16-byte) pieces

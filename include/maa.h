@@ -199,6 +199,11 @@ int maa_op_attention(maa_ctx* ctx, const float* d_q, const float* d_k, const flo
 /* ConvTranspose1d, d_x [B,Cin,L], torch weight [Cin,Cout,k] on the HOST, padding (k-stride)/2 -> [B,Cout,L*stride] */
 int maa_op_conv_transpose1d(maa_ctx* ctx, const float* d_x, int B, int Cin, int L, const float* h_w,
                             const float* h_bias, int Cout, int k, int stride, float leaky_slope, float* d_y);
+/* Kernel-only timing of one 3x3 (taps = 9) or 1x1 (taps = 1) convolution [B,H,W,Cin] -> [B,H,W,Cout] in the
+ * context's precision mode on synthetic data: `iters` back-to-back launches between two hipEvents.  pre_split = 1
+ * feeds the activation as bf16 hi/lo planes (the GroupNorm/LayerNorm output format of the bf16 modes). */
+int maa_op_bench_conv(maa_ctx* ctx, int B, int H, int W, int Cin, int Cout, int taps, int pre_split, int iters,
+                      float* ms_per_launch);
 /* BigVGAN Activation1d (up2 FIR -> snake(beta) -> down2 FIR) on d_x [B,C,L] */
 int maa_op_snake_aa(maa_ctx* ctx, const float* d_x, int B, int C, int L, const float* h_alpha, const float* h_beta,
                     int logscale, float* d_y);
