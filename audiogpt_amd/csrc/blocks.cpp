@@ -34,7 +34,6 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
     if (x1.split) {
         MAA_CHECK(!x2, "a split source cannot be concatenated");
         p.a_split = 1;
-        p.a_lo_off = x1.numel();
     }
     p.M = out.B * out.H * out.W;
     p.K = o.KH * o.KW * (p.C1 + p.C2);
@@ -74,7 +73,6 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
     p.b_lo_off = w.lo_off;
     if (a_split_rows > 0) {
         p.a_split = 1;
-        p.a_lo_off = a_split_rows * (long long)lda;
     }
     p.bias = w.bias;
     p.res = res;

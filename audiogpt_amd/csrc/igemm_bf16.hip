@@ -38,10 +38,12 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     lo = pk_bf16(a - fa, b - fb);
 }
 
-// A_SPLIT / B_SPLIT: the operand already sits in memory as two bf16 planes (hi, then lo at +lo_off elements), k
-// contiguous: GroupNorm / LayerNorm outputs and packed weights in the bf16 modes.  Its tile is then copied
-// global -> LDS as 16-byte pieces with no conversion; otherwise the operand is fp32 and is split while its tile is
-// written to LDS (once per tile, i.e. once per tap and per N-tile for a conv -- which is why producers pre-split).
+// A_SPLIT / B_SPLIT: the operand already sits in memory pre-split ("split32" format: each group of 32 consecutive k
+// of a row occupies one 128-byte line = [32 bf16 hi | 32 bf16 lo], so a row has the byte pitch of its fp32 form):
+// GroupNorm / LayerNorm outputs and packed weights in the bf16 modes.  A tile row of one K chunk is then exactly one
+// cache line, fetched once, and is copied global -> LDS as 16-byte pieces with no conversion.  Otherwise the operand
+// is fp32 and is split while its tile is written to LDS (once per tile, i.e. once per tap and per N-tile for a
+// conv -- which is why producers pre-split).
 __device__ __forceinline__ void st16(unsigned short* dst, const float4& v) {   // 16-byte LDS store, by members
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const f32x4 t = {v.x, v.y, v.z, v.w};
@@ -64,12 +66,10 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     constexpr int ROWS = BM + BN;
     constexpr int PLANE_ELEMS = ROWS * LDK;            // bf16 elements of one plane of one buffer
     // per-thread 16-byte loads per chunk: fp32 operand: rows/32 float4; split operand: (rows/64 row slots) x planes
-    constexpr int TPR_S = BK / 8, RPP_S = NT / TPR_S;  // split operand: threads per row (16 B each), rows per pass
-    constexpr int TPR_F = BK / 4, RPP_F = NT / TPR_F;  // fp32 operand: threads per row (float4 each), rows per pass
-    constexpr int ARS = A_SPLIT ? (BM >= RPP_S ? BM / RPP_S : 1) : (BM >= RPP_F ? BM / RPP_F : 1);   // row slots
-    constexpr int BRS = B_SPLIT ? (BN >= RPP_S ? BN / RPP_S : 1) : (BN >= RPP_F ? BN / RPP_F : 1);
-    constexpr int AL = A_SPLIT ? ARS * PLANES : ARS;
-    constexpr int BL = B_SPLIT ? BRS * PLANES : BRS;
+    // both operand forms: 8 threads per row, 16 bytes each = the 128-byte line of one (row, K chunk); 32 rows per pass
+    constexpr int RPP = NT / 8;
+    constexpr int ARS = BM / RPP, BRS = BN / RPP;     // row slots (= 16-byte loads) per thread per chunk
+    constexpr int AL = ARS, BL = BRS;
     static_assert(WGM * WGN == 4 && BM % 32 == 0 && BN % 32 == 0, "tile");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // [buf][plane][row][LDK]
 
@@ -90,8 +90,6 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     const float* a1 = p.a1 + zo * p.a_so + zi * p.a_si;
     const float* a2 = p.a2;
     const float* bp = p.b + zo * p.b_so + zi * p.b_si;
-    const unsigned short* a_hi = reinterpret_cast<const unsigned short*>(p.a1);
-    const unsigned short* b_hi = reinterpret_cast<const unsigned short*>(p.b);
     const long long coff = zo * p.c_so + zi * p.c_si;
 
     const int Ctot = p.C1 + p.C2;
@@ -102,10 +100,10 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     const float slope = p.a_act == 1 ? p.a_slope : 1.0f;
 
     // thread -> (row slot, k offset) for each operand form
-    const int a_r0 = A_SPLIT ? tid / TPR_S : tid / TPR_F, a_rstep = A_SPLIT ? RPP_S : RPP_F;
-    const int a_k = A_SPLIT ? (tid % TPR_S) * 8 : (tid % TPR_F) * 4;
-    const int b_r0 = B_SPLIT ? tid / TPR_S : tid / TPR_F, b_rstep = B_SPLIT ? RPP_S : RPP_F;
-    const int b_k = B_SPLIT ? (tid % TPR_S) * 8 : (tid % TPR_F) * 4;
+    const int a_r0 = tid >> 3, b_r0 = tid >> 3;
+    constexpr int a_rstep = RPP, b_rstep = RPP;
+    const int seg = tid & 7;                 // 16-byte piece of the line: fp32 -> k = 4 seg; split32 -> plane seg>>2, chunk seg&3
+    const int a_k = seg * 4, b_k = seg * 4;  // offset in fp32 units (4 bytes) for both forms
 
     // ---- A rows of this thread
     int a_b[ARS], a_iy0[ARS], a_ix0[ARS];
@@ -141,36 +139,20 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
             ix >>= p.up;
             const long long off = ok ? ((long long)a_b[j] * p.Hin + iy) * p.Win + ix : 0;
             a_ok[j] = ok;
-            if constexpr (A_SPLIT) {
-                a_p1[j] = a_hi + off * p.lda1 + a_k;
-                a_p2[j] = nullptr;
-            } else {
-                a_p1[j] = a1 + off * p.lda1 + a_k;
-                a_p2[j] = a2 + off * p.lda2 + a_k - p.C1;
-            }
+            a_p1[j] = a1 + off * p.lda1 + a_k;
+            a_p2[j] = a2 + off * p.lda2 + a_k - p.C1;
         }
     };
     auto load_a = [&](float4 (&ra)[AL]) {
-        if constexpr (A_SPLIT) {
-            const bool kin = g_ci + a_k < Ctot;
+        const bool first = g_ci < p.C1;
+        const int cend = first ? p.C1 : Ctot;
+        const bool kin = A_SPLIT ? g_ci < cend : g_ci + a_k < cend;      // split32: whole lines only (C % 32 == 0)
 #pragma unroll
-            for (int q = 0; q < AL; ++q) {
-                const int pl = q / ARS, j = q % ARS;
-                const float4* src = reinterpret_cast<const float4*>(
-                    static_cast<const unsigned short*>(a_p1[j]) + pl * p.a_lo_off + g_ci);
-                const float4 v = *((a_ok[j] && kin) ? src : g_zero4);   // (a local first: a direct struct copy
-                ra[q] = v;                                               //  into the array defeats SROA -> scratch)
-            }
-        } else {
-            const bool first = g_ci < p.C1;
-            const int cend = first ? p.C1 : Ctot;
-            const bool kin = g_ci + a_k < cend;
-#pragma unroll
-            for (int j = 0; j < ARS; ++j) {
-                const float4* src = reinterpret_cast<const float4*>(
-                    static_cast<const float*>(first ? a_p1[j] : a_p2[j]) + g_ci);
-                ra[j] = *((a_ok[j] && kin) ? src : g_zero4);
-            }
+        for (int j = 0; j < ARS; ++j) {
+            const float4* src = reinterpret_cast<const float4*>(
+                static_cast<const float*>(first ? a_p1[j] : a_p2[j]) + g_ci);
+            const float4 v = *((a_ok[j] && kin) ? src : g_zero4);   // (a local first: a direct struct copy into
+            ra[j] = v;                                               //  the array defeats SROA -> scratch)
         }
         g_ci += BK;
         if (g_ci >= Ctot && g_tap + 1 < taps) {
@@ -181,35 +163,22 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
     };
 
     // ---- B rows ([N][K], k contiguous)
-    const void* b_ptr[BRS];
+    const float* b_ptr[BRS];
     bool b_ok[BRS];
 #pragma unroll
     for (int j = 0; j < BRS; ++j) {
         const int row = b_r0 + b_rstep * j;
         const int n = n0 + row;
-        b_ok[j] = row < BN && n < Nb;
-        if constexpr (B_SPLIT)
-            b_ptr[j] = b_hi + (long long)(b_ok[j] ? n : 0) * p.ldb + b_k;
-        else
-            b_ptr[j] = bp + (long long)(b_ok[j] ? n : 0) * p.ldb + b_k;
+        b_ok[j] = n < Nb;
+        b_ptr[j] = bp + (long long)(b_ok[j] ? n : 0) * p.ldb + b_k;
     }
     auto load_b = [&](float4 (&rb)[BL], int k0) {
-        const bool kin = k0 + b_k < p.K;
-        if constexpr (B_SPLIT) {
+        const bool kin = B_SPLIT ? k0 < p.K : k0 + b_k < p.K;
 #pragma unroll
-            for (int q = 0; q < BL; ++q) {
-                const int pl = q / BRS, j = q % BRS;
-                const float4* src = reinterpret_cast<const float4*>(
-                    static_cast<const unsigned short*>(b_ptr[j]) + pl * p.b_lo_off + k0);
-                const float4 v = *((b_ok[j] && kin) ? src : g_zero4);
-                rb[q] = v;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < BRS; ++j) {
-                const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(b_ptr[j]) + k0);
-                rb[j] = *((b_ok[j] && kin) ? src : g_zero4);
-            }
+        for (int j = 0; j < BRS; ++j) {
+            const float4* src = reinterpret_cast<const float4*>(b_ptr[j] + k0);
+            const float4 v = *((b_ok[j] && kin) ? src : g_zero4);
+            rb[j] = v;
         }
     };
 
@@ -227,43 +196,32 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
             *reinterpret_cast<uint2*>(base + PLANE_ELEMS + e) = lo;
         }
     };
+    // LDS element offset of this thread's piece of row `row` for a split32 line: plane seg>>2, chunk (seg&3) swizzled
+    auto split_dst = [&](int row) { return (seg >> 2) * PLANE_ELEMS + row * LDK + (((seg & 3) ^ ((row >> 2) & 3)) << 3); };
+    auto f32_dst = [&](int row) { return row * LDK + (((seg >> 1) ^ ((row >> 2) & 3)) << 3) + (seg & 1) * 4; };
     auto store_tiles = [&](const float4 (&ra)[AL], const float4 (&rb)[BL], int buf) {
         unsigned short* base = smem + buf * PLANES * PLANE_ELEMS;
-        if constexpr (A_SPLIT) {
 #pragma unroll
-            for (int q = 0; q < AL; ++q) {
-                const int pl = q / ARS, j = q % ARS;
-                const int row = a_r0 + a_rstep * j;
-                if (BM >= RPP_S || row < BM)
-                    st16(base + pl * PLANE_ELEMS + row * LDK + (((a_k >> 3) ^ ((row >> 2) & 3)) << 3), ra[q]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < ARS; ++j) {
+        for (int j = 0; j < ARS; ++j) {
+            const int row = a_r0 + a_rstep * j;
+            if constexpr (A_SPLIT) {
+                if (PLANES == 2 || seg < 4) st16(base + split_dst(row), ra[j]);
+            } else {
                 float4 v = ra[j];
                 v.x = fmaxf(v.x, v.x * slope);
                 v.y = fmaxf(v.y, v.y * slope);
                 v.z = fmaxf(v.z, v.z * slope);
                 v.w = fmaxf(v.w, v.w * slope);
-                const int row = a_r0 + a_rstep * j;
-                if (BM >= RPP_F || row < BM)
-                    put_f32(base, row * LDK + (((a_k >> 3) ^ ((row >> 2) & 3)) << 3) + (a_k & 7), v);
+                put_f32(base, f32_dst(row), v);
             }
         }
-        if constexpr (B_SPLIT) {
 #pragma unroll
-            for (int q = 0; q < BL; ++q) {
-                const int pl = q / BRS, j = q % BRS;
-                const int row = b_r0 + b_rstep * j;
-                if (BN >= RPP_S || row < BN)
-                    st16(base + pl * PLANE_ELEMS + (BM + row) * LDK + (((b_k >> 3) ^ ((row >> 2) & 3)) << 3), rb[q]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < BRS; ++j) {
-                const int row = b_r0 + b_rstep * j;
-                if (BN >= RPP_F || row < BN)
-                    put_f32(base, (BM + row) * LDK + (((b_k >> 3) ^ ((row >> 2) & 3)) << 3) + (b_k & 7), rb[j]);
+        for (int j = 0; j < BRS; ++j) {
+            const int row = BM + b_r0 + b_rstep * j;
+            if constexpr (B_SPLIT) {
+                if (PLANES == 2 || seg < 4) st16(base + split_dst(row), rb[j]);
+            } else {
+                put_f32(base, f32_dst(row), rb[j]);
             }
         }
     };
@@ -419,8 +377,8 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     bool fast;
     if (p.a_split) {
         // bf16 planes: 8-element (16-byte) pieces
-        fast = p.C2 == 0 && Ctot % 8 == 0 && (taps == 1 || Ctot % BK == 0) && p.lda1 % 8 == 0 && al16(p.a1) &&
-               p.a_lo_off % 8 == 0 && p.Z == 1 && p.a_act == 0;
+        // split32 lines: whole 32-channel groups, rows pitched like their fp32 form
+        fast = p.C2 == 0 && Ctot % 32 == 0 && p.lda1 % 32 == 0 && al16(p.a1) && p.Z == 1 && p.a_act == 0;
     } else {
         fast = (taps == 1 ? (p.C2 == 0 ? (Ctot % 4 == 0 || p.lda1 >= (Ctot + 3) / 4 * 4)
                                        : (p.C1 % BK == 0 && Ctot % 4 == 0))
@@ -429,7 +387,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         if (p.C2 > 0) fast = fast && p.lda2 % 4 == 0 && al16(p.a2);
     }
     if (p.b_split)
-        fast = fast && p.ldb % 8 == 0 && al16(p.b) && p.b_lo_off % 8 == 0 && p.ldb >= (p.K + 7) / 8 * 8 && p.Z == 1;
+        fast = fast && p.ldb % 32 == 0 && al16(p.b) && p.K % 32 == 0 && p.ldb >= p.K && p.Z == 1;
     else
         fast = fast && p.ldb % 4 == 0 && al16(p.b) && p.b_so % 4 == 0 && p.b_si % 4 == 0 && p.ldb >= (p.K + 3) / 4 * 4;
     fast = fast && p.K == taps * Ctot && (p.a_act == 0 || p.a_act == 1);

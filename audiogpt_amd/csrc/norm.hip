@@ -37,21 +37,22 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
     bf16x2 h = __builtin_convertvector(f, bf16x2);
     return __builtin_bit_cast(unsigned, h);
 }
-// write 4 consecutive channels either as fp32 or as the bf16 hi / lo planes read by the bf16 GEMM engine
-// (hi = bf16(v), lo = bf16(v - hi); planes are `plane` ushort elements apart)
-__device__ __forceinline__ void store4(float* out, long long idx, long long plane, int split, float4 v) {
+// write 4 consecutive channels (c % 4 == 0) of row `row` either as fp32 or in the "split32" form read by the bf16
+// GEMM engine: every 32 channels of a row take one 128-byte line [32 bf16 hi | 32 bf16 lo], hi = bf16(v),
+// lo = bf16(v - hi); the row pitch is the same C*4 bytes as fp32
+__device__ __forceinline__ void store4(float* out, long long row, int c, int C, int split, float4 v) {
     if (!split) {
-        *reinterpret_cast<float4*>(out + idx) = v;
+        *reinterpret_cast<float4*>(out + row * C + c) = v;
         return;
     }
-    unsigned short* o = reinterpret_cast<unsigned short*>(out);
+    unsigned short* o = reinterpret_cast<unsigned short*>(out) + row * C * 2 + (c >> 5) * 64 + (c & 31);
     uint2 hi, lo;
     hi.x = pk_bf16(v.x, v.y);
     hi.y = pk_bf16(v.z, v.w);
     lo.x = pk_bf16(v.x - __builtin_bit_cast(float, hi.x << 16), v.y - __builtin_bit_cast(float, hi.x & 0xffff0000u));
     lo.y = pk_bf16(v.z - __builtin_bit_cast(float, hi.y << 16), v.w - __builtin_bit_cast(float, hi.y & 0xffff0000u));
-    *reinterpret_cast<uint2*>(o + idx) = hi;
-    *reinterpret_cast<uint2*>(o + plane + idx) = lo;
+    *reinterpret_cast<uint2*>(o) = hi;
+    *reinterpret_cast<uint2*>(o + 32) = lo;
 }
 
 // GroupNorm pass 1: one block per (sample, group) -> stats[(b*groups+g)*2] = {mean, rstd}; threads = (position
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ beta, const float* __restrict__ stats,
                                                        int silu, float* __restrict__ out, int split) {
     const int C = C1 + C2, cpg = C / groups, c4n = C / 4;
-    const long long total = rows * c4n, plane = rows * C;
+    const long long total = rows * c4n;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long row = i / c4n;
         const int c = (int)(i - row * c4n) * 4;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             if (silu) y = y / (1.f + expf(-y));
             o[e] = y;
         }
-        store4(out, row * C + c, plane, split, make_float4(o[0], o[1], o[2], o[3]));
+        store4(out, row, c, C, split, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             y.y = (v[i].y - mean) * rstd * g.y + bt.y;
             y.z = (v[i].z - mean) * rstd * g.z + bt.z;
             y.w = (v[i].w - mean) * rstd * g.w + bt.w;
-            store4(out, row * C + c, rows * C, split, y);
+            store4(out, row, c, C, split, y);
         }
     }
 }

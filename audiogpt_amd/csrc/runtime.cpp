@@ -172,22 +172,23 @@ void* WeightStore::upload_raw(const void* host, size_t bytes) {
 
 void WeightStore::finish(PackedW& pw, const std::vector<float>& kn, bool bf16_ok) {
     if (nk_ && bf16_ok) {
-        // pre-split planes [2][Npad][K8]: hi = bf16(w), lo = bf16(w - hi); the kernel copies them straight to LDS
-        const int K8 = (pw.K + 7) / 8 * 8;
-        const size_t plane = (size_t)pw.Npad * K8;
-        std::vector<unsigned short> t(2 * plane, 0);
+        // pre-split "split32" rows [Npad][K]: every 32 k of a row are one 128-byte line [32 hi | 32 lo] with
+        // hi = bf16(w), lo = bf16(w - hi); the kernel copies the lines straight to LDS.  ld is in fp32 units.
+        MAA_CHECK(pw.K % 32 == 0, "split32 weights need K % 32 == 0");
+        std::vector<unsigned short> t((size_t)pw.Npad * pw.K * 2, 0);
         for (int k = 0; k < pw.K; ++k)
             for (int n = 0; n < pw.Npad; ++n) {
                 const float w = kn[(size_t)k * pw.Npad + n];
                 const unsigned short hi = f2bf(w);
-                t[(size_t)n * K8 + k] = hi;
-                t[plane + (size_t)n * K8 + k] = f2bf(w - bf2f(hi));
+                const size_t at = (size_t)n * pw.K * 2 + (size_t)(k >> 5) * 64 + (k & 31);
+                t[at] = hi;
+                t[at + 32] = f2bf(w - bf2f(hi));
             }
         pw.w = static_cast<float*>(upload_raw(t.data(), t.size() * sizeof(unsigned short)));
-        pw.ld = K8;
+        pw.ld = pw.K;
         pw.nk = 1;
         pw.split = 1;
-        pw.lo_off = (long long)plane;
+        pw.lo_off = 0;
         return;
     }
     if (!nk_) {
@@ -220,7 +221,7 @@ PackedW WeightStore::pack_conv(const StateDict& sd, const std::string& wname, co
         for (int ci = 0; ci < Cin; ++ci)
             for (int t = 0; t < KH * KW; ++t)
                 h[((size_t)t * Cin + ci) * pw.Npad + co] = w.data[((size_t)co * Cin + ci) * KH * KW + t];
-    finish(pw, h, KH * KW == 1 ? Cin % 8 == 0 : Cin % 32 == 0);
+    finish(pw, h, Cin % 32 == 0);
     if (!bname.empty()) {
         const HostTensor& b = get(sd, bname);
         std::vector<float> hb(pw.Npad, 0.f);
@@ -257,7 +258,7 @@ PackedW WeightStore::pack_concat(const StateDict& sd, const std::vector<std::str
         }
         col += co_n;
     }
-    finish(pw, h, Cin % 8 == 0);
+    finish(pw, h, Cin % 32 == 0);
     bool any_bias = false;
     for (auto& b : bnames) any_bias = any_bias || !b.empty();
     if (any_bias) pw.bias = upload(hb);
@@ -287,7 +288,7 @@ PackedW WeightStore::pack_geglu(const StateDict& sd, const std::string& wname, c
         hb[cv] = b.data[j];
         hb[cg] = b.data[inner + j];
     }
-    finish(pw, h, Cin % 8 == 0);
+    finish(pw, h, Cin % 32 == 0);
     pw.bias = upload(hb);
     return pw;
 }
