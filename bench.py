@@ -14,8 +14,9 @@ conditioning for all ranks and broadcasts it over RCCL, waveforms are gathered t
 inside the DDIM loop.
 
 Output: ONE JSON line on rank 0 with metric/value plus
-  roofline     -- the dominant kernel (fp32-MFMA implicit GEMM): algorithmic FLOPs of its launches / their summed
-                  hipEvent durations, against the 157.3 TFLOP/s fp32 matrix peak of gfx950
+  roofline     -- the dominant kernel (the implicit-GEMM engine): algorithmic FLOPs (2*M*N*K) of its launches / their
+                  summed hipEvent durations, against the dense MFMA peak of the precision mode (157.3 TFLOP/s fp32,
+                  2500 TFLOP/s bf16; bf16x3 spends 3 MFMAs per algorithmic multiply-add)
   cpu_baseline -- the CPU oracle (a port of the reference path) on this box's host cores, bounded sample
 """
 import argparse
@@ -34,7 +35,10 @@ if ROOT not in sys.path:
 from audiogpt_amd import config as C            # noqa: E402
 from audiogpt_amd import weights as WT          # noqa: E402
 
-PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# MI355X_MICROARCH.md: dense MFMA peaks.  The bf16x3 mode issues 3 bf16 MFMAs per algorithmic multiply-add
+# (hi*hi + hi*lo + lo*hi), so its algorithmic ceiling is a third of the bf16 MFMA peak.
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0, "bf16": 2500.0}
+MFMA_PER_FLOP = {"f32": 1, "bf16x3": 3, "bf16": 1}
 CLIP_FRAMES = 624
 LATENT = (4, 10, 78)
 DDIM_STEPS = 100
@@ -162,9 +166,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic prompts (layer-normed N(0,1) [B,77,1024]); seeded random-init weights",
+        "dtype": args.precision, "data": "synthetic prompts (layer-normed N(0,1) [B,77,1024]); seeded random-init weights",
         "config": {"workload": "Make-An-Audio T2A batch=%d/GPU, %d DDIM steps, CFG %.1f, UNet+VAE+HiFi-GAN(16k), "
-                               "fp32 (exact-f32 MFMA)" % (n, S, CFG_SCALE),
+                               "%s" % (n, S, CFG_SCALE, {"f32": "fp32 (exact-f32 MFMA)", "bf16x3": "fp32 storage, bf16x3-split MFMA (hi/lo, fp32 accumulate; meets the fp32 parity gates)", "bf16": "fp32 storage, bf16 MFMA operands"}[args.precision]),
                    "prompts_per_gpu": n, "ddim_steps": S, "latent": list(LATENT), "mel_frames": CLIP_FRAMES,
                    "audio_seconds_per_step": pipe.audio_seconds(n * world, CLIP_FRAMES), "hipgraph": use_graph,
                    "parallelism": "prompt-sharded x%d (RCCL bcast cond / gather wav)" % world},
@@ -180,19 +184,32 @@ def main():
         pipe.generate(x_T, c, uc, CFG_SCALE, S, use_graph=False)
         rows = pipe.ctx.prof_end()
         total_ms = sum(r["ms"] for r in rows.values())
-        ig = {k: v for k, v in rows.items() if k.startswith("igemm_f32")}
+        ig = {k: v for k, v in rows.items() if k.startswith("igemm")}
         dom = max(ig, key=lambda k: ig[k]["ms"])
         ig_ms = sum(v["ms"] for v in ig.values())
         ig_fl = sum(v["flops"] for v in ig.values())
         d = ig[dom]
+        peak = PEAK_TFLOPS[args.precision]
+        per = MFMA_PER_FLOP[args.precision] if "bf16" in dom else 1
+        if "f32" in dom:
+            peak = PEAK_TFLOPS["f32"]
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_note = None, None
+        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                t = json.load(f)
+            if t.get("precision") == args.precision and t.get("kernel_family") == dom.split("<")[0]:
+                traffic, traffic_note = t["hbm_bytes_per_launch"], t["note"]
         result["roofline"] = {
             "bound": "mfma", "kernel": dom,
-            "achieved": d["flops"] / (d["ms"] * 1e-3) / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": d["flops"] / (d["ms"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS, "traffic": None,
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "mfma_ops_per_algorithmic_flop": per, "frac_of_mfma_issue_peak": ach * per / peak,
+            "traffic": traffic, "traffic_note": traffic_note,
             "launches": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"],
             "flops_per_launch_avg": d["flops"] / d["launches"],
-            "all_igemm": {"achieved": ig_fl / (ig_ms * 1e-3) / 1e12, "frac": ig_fl / (ig_ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS,
-                          "ms": ig_ms, "tflop": ig_fl / 1e12, "share_of_kernel_time": ig_ms / total_ms},
+            "all_igemm": {"achieved": ig_fl / (ig_ms * 1e-3) / 1e12, "ms": ig_ms, "tflop": ig_fl / 1e12,
+                          "share_of_kernel_time": ig_ms / total_ms},
             "kernel_time_ms": {k: round(v["ms"], 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])},
         }
         if args.breakdown:
