@@ -56,7 +56,9 @@ __device__ __forceinline__ void store4(float* out, long long row, int c, int C, 
 }
 
 // GroupNorm pass 1: one block per (sample, group) -> stats[(b*groups+g)*2] = {mean, rstd}; threads = (position
-// lane, channel-in-group); mean first, then the centred second moment (as accurate as ATen's)
+// lane, channel-in-group).  One pass over the data: sums of d = x - pivot and d*d, with the group's first element as
+// pivot (so the subtraction var = E[d^2] - E[d]^2 cancels at most a couple of bits, like the two-pass form), four
+// independent loads in flight per thread.  Fixed reduction order: results are bit-reproducible.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x1, int ld1, int C1,
                                                        const float* __restrict__ x2, int ld2, int C2, int HW,
                                                        int groups, float eps, float* __restrict__ stats) {
@@ -76,20 +78,35 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
         src = x2 + (long long)b * HW * ld2 + (c - C1);
         ld = ld2;
     }
+    const int c0 = g * cpg;
+    const float pivot = c0 < C1 ? x1[(long long)b * HW * ld1 + c0] : x2[(long long)b * HW * ld2 + (c0 - C1)];
     const float n = (float)HW * (float)cpg;
-    float s = 0.f;
-    if (active)
-        for (int pos = tp; pos < HW; pos += tp_n) s += src[pos * ld];
-    const float mean = block_sum(s, red) / n;
-    float q = 0.f;
-    if (active)
-        for (int pos = tp; pos < HW; pos += tp_n) {
-            const float d = src[pos * ld] - mean;
-            q += d * d;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+    if (active) {
+        int pos = tp;
+        for (; pos + 3 * tp_n < HW; pos += 4 * tp_n) {
+            const float d0 = src[pos * ld] - pivot, d1 = src[(pos + tp_n) * ld] - pivot;
+            const float d2 = src[(pos + 2 * tp_n) * ld] - pivot, d3 = src[(pos + 3 * tp_n) * ld] - pivot;
+            s0 += d0;
+            s1 += d1;
+            s2 += d2;
+            s3 += d3;
+            q0 += d0 * d0;
+            q1 += d1 * d1;
+            q2 += d2 * d2;
+            q3 += d3 * d3;
         }
-    const float var = block_sum(q, red) / n;
+        for (; pos < HW; pos += tp_n) {
+            const float d0 = src[pos * ld] - pivot;
+            s0 += d0;
+            q0 += d0 * d0;
+        }
+    }
+    const float sm = block_sum((s0 + s1) + (s2 + s3), red) / n;
+    const float qm = block_sum((q0 + q1) + (q2 + q3), red) / n;
     if (threadIdx.x == 0) {
-        stats[2 * blockIdx.x] = mean;
+        const float var = fmaxf(qm - sm * sm, 0.f);
+        stats[2 * blockIdx.x] = pivot + sm;
         stats[2 * blockIdx.x + 1] = 1.f / sqrtf(var + eps);
     }
 }
