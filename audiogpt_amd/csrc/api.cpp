@@ -467,6 +467,38 @@ int maa_op_bench_conv(maa_ctx* ctx, int B, int H, int W, int Cin, int Cout, int 
             s = s * 1664525u + 1013904223u;
             v = ((int)(s >> 9) % 2001 - 1000) * 1e-3f;
         }
+        if (pre_split && c.dtype != 0) {
+            // rewrite the rows as split32 lines ([32 bf16 hi | 32 bf16 lo] per 32 channels), the GroupNorm output form
+            MAA_CHECK(Cin % 32 == 0, "op_bench_conv: pre-split input needs Cin % 32 == 0");
+            auto f2bf = [](float f) {
+                unsigned u;
+                std::memcpy(&u, &f, 4);
+                u += 0x7fffu + ((u >> 16) & 1u);
+                return (unsigned short)(u >> 16);
+            };
+            std::vector<float> packed(n_in);
+            unsigned short* d = reinterpret_cast<unsigned short*>(packed.data());
+            for (size_t g = 0; g < n_in / 32; ++g)
+                for (int j = 0; j < 32; ++j) {
+                    const float v = hx[g * 32 + j];
+                    const unsigned short h = f2bf(v);
+                    const unsigned hu = (unsigned)h << 16;
+                    float hf;
+                    std::memcpy(&hf, &hu, 4);
+                    d[g * 64 + j] = h;
+                    d[g * 64 + 32 + j] = f2bf(v - hf);
+                }
+            hx.swap(packed);
+        }
+        int x_ld = 0;
+        static const int apad = std::getenv("MAA_APAD") ? std::atoi(std::getenv("MAA_APAD")) : 0;   // experiment
+        if (apad > 0) {
+            std::vector<float> pitched((size_t)B * H * W * (Cin + apad), 0.f);
+            for (size_t r = 0; r < (size_t)B * H * W; ++r)
+                std::memcpy(&pitched[r * (Cin + apad)], &hx[r * Cin], sizeof(float) * Cin);
+            hx.swap(pitched);
+            x_ld = Cin + apad;
+        }
         float* dx = ws.upload(hx);
         float* dy = ws.upload(std::vector<float>(n_out, 0.f));
         maa::T4 x, y;
@@ -476,10 +508,9 @@ int maa_op_bench_conv(maa_ctx* ctx, int B, int H, int W, int Cin, int Cout, int 
         x.C = Cin;
         y.C = Cout;
         x.p = dx;
+        x.ld = x_ld;
         y.p = dy;
         if (pre_split && c.dtype != 0) {
-            // reinterpret the same bytes as bf16 planes: arbitrary but finite bf16 values (both fp32 halves are
-            // valid bf16 bit patterns of small numbers), enough for timing
             x.split = true;
         }
         maa::ConvOpt o;

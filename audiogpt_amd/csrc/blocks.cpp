@@ -5,7 +5,7 @@ namespace maa {
 void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const ConvOpt& o, T4& out) {
     IGemm p;
     p.a1 = x1.p;
-    p.lda1 = x1.C;
+    p.lda1 = x1.ld ? x1.ld : x1.C;
     p.C1 = x1.C;
     if (x2) {
         MAA_CHECK(x2->B == x1.B && x2->H == x1.H && x2->W == x1.W, "concat sources differ in shape");
@@ -55,7 +55,7 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
 }
 
 void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const PackedW& w, const float* res,
-                 int ldr, float* out, int ldc, int geglu, int a_act, long long a_split_rows) {
+                 int ldr, float* out, int ldc, int geglu, int a_act, long long a_split_rows, int c_split) {
     IGemm p;
     p.a1 = a;
     p.lda1 = lda;
@@ -79,14 +79,19 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
     p.ldr = ldr;
     p.geglu = geglu;
     p.a_act = a_act;
+    p.c_split = c_split;
     p.c = out;
     p.ldc = ldc;
     launch_igemm(ctx, p);
 }
 
 void attention_into(Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk, const float* v,
-                    int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha, float* out, int ldo) {
-    if (launch_flash_attention(ctx, q, ldq, hsq, k, ldk, hsk, v, ldv, hsv, B, heads, dh, Nq, Nk, alpha, out, ldo)) return;
+                    int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha, float* out, int ldo,
+                    int out_split) {
+    if (launch_flash_attention(ctx, q, ldq, hsq, k, ldk, hsk, v, ldv, hsv, B, heads, dh, Nq, Nk, alpha, out, ldo,
+                               out_split))
+        return;
+    MAA_CHECK(!out_split, "split32 attention output needs the fused kernel");
     const size_t mk = ctx.ws.mark();
     const int ldS = (Nk + 3) / 4 * 4;
     float* S = ctx.ws.alloc_f((size_t)B * heads * Nq * ldS);

@@ -8,7 +8,8 @@ namespace maa {
 struct T4 {              // dense channels-last activation [B, H, W, C] (sequences: H = 1)
     float* p = nullptr;
     int B = 0, H = 0, W = 0, C = 0;
-    bool split = false;  // true: p holds two bf16 planes [B*H*W][C] (hi then lo) instead of fp32 -- same byte size
+    bool split = false;  // true: rows are split32 lines ([32 bf16 hi | 32 bf16 lo] per 32 channels) instead of fp32
+    int ld = 0;          // row pitch in floats; 0 = dense (C)
     long long numel() const { return (long long)B * H * W * C; }
     long long rows() const { return (long long)B * H * W; }
 };
@@ -42,14 +43,17 @@ struct ConvOpt {
 void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const ConvOpt& o, T4& out);
 // linear over rows of a [rows, K] matrix (any leading layout, row pitch lda)
 void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const PackedW& w, const float* res,
-                 int ldr, float* out, int ldc, int geglu = 0, int a_act = 0, long long a_split_rows = 0);
-// a_split_rows > 0: `a` is a split-plane matrix of that many rows (lda in bf16 elements)
+                 int ldr, float* out, int ldc, int geglu = 0, int a_act = 0, long long a_split_rows = 0,
+                 int c_split = 0);
+// a_split_rows > 0: `a` holds split32 rows (row pitch lda floats);  c_split: write `out` as split32 rows
 
 // softmax(alpha * Q K^T) V for `heads` heads of width dh stored head-major inside rows of q/k/v
 //   q: [B, Nq, *] pitch ldq;  k, v: [B, Nk, *] pitch ldk / ldv;  per-head column offset = h * head_stride_{q,k,v}
 //   out: [B, Nq, heads*dh] dense
 void attention_into(Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk, const float* v,
-                    int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha, float* out, int ldo);
+                    int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha, float* out, int ldo,
+                    int out_split = 0);
+// out_split: write split32 rows (only where flash_attention_covers(ctx, dh))
 
 // In the bf16 modes a normalisation whose only consumer is a bf16-engine contraction writes bf16 hi/lo planes
 // (no per-tile re-splitting of the same activation for every tap and N-tile)

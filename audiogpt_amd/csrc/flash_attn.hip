@@ -32,6 +32,7 @@ struct FlashArgs {
     float scale;
     float* out;
     int ldo;
+    int out_split;                // write split32 lines (the to_out projection reads them with no conversion)
     long long o_bs;
     const float* zeros;
 };
@@ -278,7 +279,21 @@ __global__ __launch_bounds__(NT) void flash_attn_kernel(const FlashArgs a) {
     float* op = a.out + b * a.o_bs + h * DH;
     for (int i = lane; i < 32 * DH; i += 64) {
         const int qi = i / DH, d = i - qi * DH;
-        if (q0 + qi < a.Nq) op[(long long)(q0 + qi) * a.ldo + d] = ot[qi * (DM + 1) + d];
+        if (q0 + qi < a.Nq) {
+            const float val = ot[qi * (DM + 1) + d];
+            if (a.out_split) {
+                const int c = h * DH + d;
+                unsigned short* o = reinterpret_cast<unsigned short*>(a.out + b * a.o_bs + (long long)(q0 + qi) * a.ldo) +
+                                    (c >> 5) * 64 + (c & 31);
+                const __bf16 hv = (__bf16)val;
+                const unsigned short hb = __builtin_bit_cast(unsigned short, hv);
+                const __bf16 lv = (__bf16)(val - __builtin_bit_cast(float, (unsigned)hb << 16));
+                o[0] = hb;
+                o[32] = __builtin_bit_cast(unsigned short, lv);
+            } else {
+                op[(long long)(q0 + qi) * a.ldo + d] = val;
+            }
+        }
     }
 }
 
@@ -300,12 +315,15 @@ void launch_dh(const Ctx& ctx, const FlashArgs& a, int B) {
 
 }  // namespace
 
+bool flash_attention_covers(const Ctx& ctx, int dh) {
+    return ctx.dtype != 0 && (dh == 32 || dh == 40 || dh == 64 || dh == 80);
+}
+
 // false: shape not covered (head dim other than 32 / 40 / 64 / 80, unaligned rows) -> caller uses the GEMM path
 bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
                             const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,
-                            float* out, int ldo) {
-    if (ctx.dtype == 0) return false;
-    if (dh != 32 && dh != 40 && dh != 64 && dh != 80) return false;
+                            float* out, int ldo, int out_split) {
+    if (!flash_attention_covers(ctx, dh)) return false;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (ldq % 4 || ldk % 4 || ldv % 4 || hsq % 4 || hsk % 4 || hsv % 4 || !al16(q) || !al16(k) || !al16(v)) return false;
     if (ctx.ws.dry) return true;
@@ -328,6 +346,7 @@ bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, co
     a.scale = alpha;
     a.out = out;
     a.ldo = ldo;
+    a.out_split = out_split;
     a.o_bs = (long long)Nq * ldo;
     a.zeros = ctx.zeros;
     const double flops = 4.0 * B * heads * (double)Nq * Nk * dh;

@@ -50,9 +50,12 @@ __device__ __forceinline__ void st16(unsigned short* dst, const float4& v) {   /
     *reinterpret_cast<f32x4*>(dst) = t;
 }
 
-// BK: K depth of one LDS stage (32 or 64); NBUF: LDS stages (2 = one barrier per chunk, 1 = half the LDS and two
-// barriers per chunk, which admits twice the workgroups per CU)
-template <int BM, int BN, int WGM, int WGN, int TERMS, bool A_SPLIT, bool B_SPLIT, int BK, int NBUF>
+// BK: K depth of one LDS stage (32).  PF: register prefetch depth in K chunks (even).  The tile loads of chunk c + PF
+// are issued before the MFMAs of chunk c and are first needed PF chunk-times later, when they are copied to LDS.
+// Most of them miss L2 on first touch (a conv's weights alone are 3-4x one XCD's L2, and every XCD streams all of
+// them), so a load takes ~2000 cycles: with PF = 2 a 64x64 chunk could not go faster than ~1000 cycles -- five times
+// its MFMA time.  vmcnt retires in order, so only more register sets (or more waves) put more bytes in flight.
+template <int BM, int BN, int WGM, int WGN, int TERMS, bool A_SPLIT, bool B_SPLIT, int BK, int PF>
 __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntiles, int Nb) {
     // LDS rows are 64 B (32 bf16) with NO padding; the 16-byte chunk c of row r is stored at chunk c ^ ((r >> 2) & 3).
     // That XOR swizzle makes both the ds_write_b128 of the staging pass (8-lane groups = two rows = 32 distinct
@@ -278,57 +281,43 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
         }
     };
 
-    // ---- main loop (same two-ahead register pipeline as the fp32 kernel)
+    // ---- main loop: PF register sets in flight, two LDS stages, one barrier per chunk
+    static_assert(PF % 2 == 0 && PF >= 2, "prefetch depth");
     const int nchunks = (p.K + BK - 1) / BK;
-    float4 ra0[AL], rb0[BL], ra1[AL], rb1[BL];
+    float4 ra[PF][AL], rb[PF][BL];
     set_tap(0);
-    load_a(ra0);
-    load_b(rb0, 0);
-    load_a(ra1);
-    load_b(rb1, BK);
-    if constexpr (NBUF == 2) {
-        store_tiles(ra0, rb0, 0);
-        __syncthreads();
-        for (int c = 0; c < nchunks; c += 2) {
-            load_a(ra0);
-            load_b(rb0, (c + 2) * BK);
-            compute(0);
-            store_tiles(ra1, rb1, 1);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        load_a(ra[u]);
+        load_b(rb[u], u * BK);
+    }
+    store_tiles(ra[0], rb[0], 0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            // chunk c + u sits in LDS stage u & 1; set u is free again
+            if (!(p.dbg & 2)) {
+                load_a(ra[u]);
+                load_b(rb[u], (c + u + PF) * BK);
+            }
+            if (c + u < nchunks && !(p.dbg & 1)) compute(u & 1);
+            if (!(p.dbg & 4)) store_tiles(ra[(u + 1) % PF], rb[(u + 1) % PF], (u + 1) & 1);
             __syncthreads();
-            load_a(ra1);
-            load_b(rb1, (c + 3) * BK);
-            compute(1);
-            store_tiles(ra0, rb0, 0);
-            __syncthreads();
-        }
-    } else {
-        for (int c = 0; c < nchunks; c += 2) {
-            __syncthreads();                 // every wave is done reading the stage
-            store_tiles(ra0, rb0, 0);
-            __syncthreads();
-            load_a(ra0);
-            load_b(rb0, (c + 2) * BK);
-            compute(0);
-            __syncthreads();
-            store_tiles(ra1, rb1, 0);
-            __syncthreads();
-            load_a(ra1);
-            load_b(rb1, (c + 3) * BK);
-            compute(0);
         }
     }
 
     igemm_epilogue<MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lrow, lk, coff, Nb, rpb);
 }
 
-template <int BM, int BN, int WGM, int WGN, int TERMS, bool AS, bool BS, int BKT, int NBUF>
+template <int BM, int BN, int WGM, int WGN, int TERMS, bool AS, bool BS, int BKT, int PF>
 void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
     const int ncols = p.N * (p.geglu ? 2 : 1);
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (ncols + BN - 1) / BN;
     dim3 grid((unsigned)((long long)mtiles * ntiles), (unsigned)p.Z);
     constexpr int planes = TERMS == 1 ? 1 : 2;
-    constexpr size_t lds = (size_t)NBUF * planes * (BM + BN) * BKT * sizeof(unsigned short);
-    auto kern = igemm_bf16_kernel<BM, BN, WGM, WGN, TERMS, AS, BS, BKT, NBUF>;
+    constexpr size_t lds = (size_t)2 * planes * (BM + BN) * BKT * sizeof(unsigned short);
+    auto kern = igemm_bf16_kernel<BM, BN, WGM, WGN, TERMS, AS, BS, BKT, PF>;
     static bool attr_set = false;
     if (!attr_set) {
         MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -337,29 +326,31 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, p, ntiles, Nb);
 }
 
-template <int TERMS, bool AS, bool BS, int BKT, int NBUF>
+template <int TERMS, bool AS, bool BS, int BKT>
 void launch_tile(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
+    // (PF = 4 was tried on the 64-wide tiles: no gain on L2-warm micro-benchmarks and 10 % slower inside the UNet,
+    //  where its extra 32 VGPRs cost a wave per SIMD)
     switch (cfg) {
-        case 0: launch_one<128, 128, 2, 2, TERMS, AS, BS, BKT, NBUF>(ctx, p, Nb); break;
-        case 1: launch_one<128, 64, 2, 2, TERMS, AS, BS, BKT, NBUF>(ctx, p, Nb); break;
-        case 2: launch_one<64, 64, 2, 2, TERMS, AS, BS, BKT, NBUF>(ctx, p, Nb); break;
-        default: launch_one<256, 32, 4, 1, TERMS, AS, BS, BKT, NBUF>(ctx, p, Nb); break;
+        case 0: launch_one<128, 128, 2, 2, TERMS, AS, BS, BKT, 2>(ctx, p, Nb); break;
+        case 1: launch_one<128, 64, 2, 2, TERMS, AS, BS, BKT, 2>(ctx, p, Nb); break;
+        case 2: launch_one<64, 64, 2, 2, TERMS, AS, BS, BKT, 2>(ctx, p, Nb); break;
+        default: launch_one<256, 32, 4, 1, TERMS, AS, BS, BKT, 2>(ctx, p, Nb); break;
     }
 }
 
-template <int TERMS, int BKT, int NBUF>
+template <int TERMS, int BKT>
 void launch_split(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
     if (p.a_split && p.b_split)
-        launch_tile<TERMS, true, true, BKT, NBUF>(ctx, p, cfg, Nb);
+        launch_tile<TERMS, true, true, BKT>(ctx, p, cfg, Nb);
     else if (p.b_split)
-        launch_tile<TERMS, false, true, BKT, NBUF>(ctx, p, cfg, Nb);
+        launch_tile<TERMS, false, true, BKT>(ctx, p, cfg, Nb);
     else
-        launch_tile<TERMS, false, false, BKT, NBUF>(ctx, p, cfg, Nb);
+        launch_tile<TERMS, false, false, BKT>(ctx, p, cfg, Nb);
 }
 
 template <int TERMS>
 void launch_terms(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
-    launch_split<TERMS, 32, 2>(ctx, p, cfg, Nb);
+    launch_split<TERMS, 32>(ctx, p, cfg, Nb);
 }
 
 }  // namespace
@@ -406,21 +397,30 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     } else {
         cfg = choose_tile(p.M, ncols, p.Z, true);
     }
+    static const bool no_dma = std::getenv("MAA_NO_DMA") != nullptr;      // tests: same arithmetic, register staging
+    const bool dma = terms == 3 && p.a_split && p.b_split && cfg != 3 && !no_dma;
+    if (dma) cfg = igemm_dma_tile(p, cfg);
     const double flops = 2.0 * p.M * (double)ncols * p.K * p.Z;
     const double bytes = 4.0 * ((double)p.K * ncols + (double)p.M * p.N * p.Z);
+    static const char* kNamesD[3] = {"igemm_dma_bf16x3<128x128>", "igemm_dma_bf16x3<128x64>", "igemm_dma_bf16x3<64x64>"};
     static const char* kNames3[4] = {"igemm_bf16x3<128x128>", "igemm_bf16x3<128x64>", "igemm_bf16x3<64x64>", "igemm_bf16x3<256x32>"};
     static const char* kNames1[4] = {"igemm_bf16<128x128>", "igemm_bf16<128x64>", "igemm_bf16<64x64>", "igemm_bf16<256x32>"};
     char shape_name[48];
-    const char* pname = terms == 3 ? kNames3[cfg] : kNames1[cfg];
+    const char* pname = dma ? kNamesD[cfg] : terms == 3 ? kNames3[cfg] : kNames1[cfg];
     if (ctx.prof && ctx.prof->detail) {
-        std::snprintf(shape_name, sizeof(shape_name), "bg%d M%d N%d K%d t%d Z%d", cfg, p.M, ncols, p.K, taps, p.Z);
+        std::snprintf(shape_name, sizeof(shape_name), "b%c%d M%d N%d K%d t%d Z%d", dma ? 'd' : 'g', cfg, p.M, ncols, p.K, taps, p.Z);
         pname = shape_name;
     }
     ProfScope prof(ctx, pname, flops, bytes);
-    if (terms == 3)
-        launch_terms<3>(ctx, p, cfg, Nb);
+    static const int dbg = std::getenv("MAA_DBG") ? std::atoi(std::getenv("MAA_DBG")) : 0;   // ablation runs only
+    IGemm q = p;
+    q.dbg = dbg;
+    if (dma)
+        launch_igemm_dma(ctx, q, cfg, Nb);
+    else if (terms == 3)
+        launch_terms<3>(ctx, q, cfg, Nb);
     else
-        launch_terms<1>(ctx, p, cfg, Nb);
+        launch_terms<1>(ctx, q, cfg, Nb);
     MAA_HIP(hipGetLastError());
     return true;
 }

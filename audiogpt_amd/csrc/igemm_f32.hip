@@ -367,6 +367,7 @@ void launch_igemm(const Ctx& ctx, const IGemm& p_in) {
     if (ctx.dtype == 1 && launch_igemm_bf16(ctx, p, 3)) return;
     if (ctx.dtype == 2 && launch_igemm_bf16(ctx, p, 1)) return;
     MAA_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty igemm");
+    MAA_CHECK(!p.c_split, "split32 output asked of a problem only the fp32 engine can take");
     const int taps = p.KH * p.KW, Ctot = p.C1 + p.C2;
     MAA_CHECK(p.K <= taps * Ctot && p.K > (taps - 1) * Ctot, "igemm K mismatch");
     MAA_CHECK(p.a_act == 0 || p.a_act == 1, "igemm A activation");

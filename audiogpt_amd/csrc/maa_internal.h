@@ -128,9 +128,11 @@ struct IGemm {
     int act = 0;                     // 0 none, 1 tanh
     float out_scale = 1.f;           // applied after bias/residual/act
     int accumulate = 0;              // c += value instead of c = value
+    int c_split = 0;                 // write the output as split32 lines (bf16 engine only; no accumulate, Z == 1)
     float* c = nullptr;
     int ldc = 0;
     const float* zeros = nullptr;    // >= 16 B of zeros in device memory (filled in by launch_igemm)
+    int dbg = 0;                     // timing ablations (MAA_DBG): 1 skip MFMA phase, 2 skip tile loads, 4 skip LDS stores (DMA engine: barrier), 8 skip the DMA wait
 };
 void launch_igemm(const Ctx& ctx, const IGemm& p);
 // Tile choice shared by the fp32 and bf16 engines: 0 = 128x128, 1 = 128x64, 2 = 64x64 (3 = 256x32 is chosen by
@@ -138,12 +140,15 @@ void launch_igemm(const Ctx& ctx, const IGemm& p);
 // co-resident blocks per CU); knobs can be overridden for tuning with MAA_TILE_EFF / MAA_CONC_EFF / MAA_FORCE_CFG.
 int choose_tile(long long M, long long N, int Z, bool bf16);
 bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms);   // false: not eligible, use the fp32 kernel
+// bf16x3 with LDS-DMA tile copies, both operands split32 (igemm_dma.hip); called by launch_igemm_bf16
+int igemm_dma_tile(const IGemm& p, int cfg);      // tile the DMA engine runs for the generic choice `cfg`
+void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb);
 
 // ------------------------------------------------------------------------------------------ norms etc.
 // GroupNorm(32 groups) over a channels-last tensor given as a virtual concat of two sources; writes
 // a dense [B, HW, C1+C2] tensor.  silu: fuse x*sigmoid(x).
 // out_split = 1: the output is written as two bf16 planes (hi, then lo at +B*HW*C ushort elements) for a bf16-engine
-// consumer instead of fp32 (same byte size).  Takes 2*B*groups floats of scratch from the arena.
+// consumer instead of fp32 (same byte size).  Takes 2*B*C floats of scratch (per-sample channel scale/shift) from the arena.
 void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int B, int HW,
                       int groups, const float* gamma, const float* beta, float eps, int silu, float* out,
                       int out_split = 0);
@@ -152,7 +157,8 @@ void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, con
 // fused softmax(alpha q k^T) v for the bf16 precision modes; false = shape not covered, use the GEMM path
 bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
                             const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,
-                            float* out, int ldo);
+                            float* out, int ldo, int out_split = 0);
+bool flash_attention_covers(const Ctx& ctx, int dh);    // head widths launch_flash_attention takes in this mode
 // in-place row softmax over `cols` columns of a [rows, ld] matrix; columns [cols, ld) are zeroed
 void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld);
 

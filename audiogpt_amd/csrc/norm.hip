@@ -55,14 +55,17 @@ __device__ __forceinline__ void store4(float* out, long long row, int c, int C, 
     *reinterpret_cast<uint2*>(o + 32) = lo;
 }
 
-// GroupNorm pass 1: one block per (sample, group) -> stats[(b*groups+g)*2] = {mean, rstd}; threads = (position
+// GroupNorm pass 1: one block per (sample, group) -> tab[(b*C + c)*2] = {scale, shift} for the group's channels
+// (scale = gamma*rstd, shift = beta - mean*scale, as ATen forms them); threads = (position
 // lane, channel-in-group).  One pass over the data: sums of d = x - pivot and d*d, with the group's first element as
 // pivot (so the subtraction var = E[d^2] - E[d]^2 cancels at most a couple of bits, like the two-pass form), four
 // independent loads in flight per thread.  Fixed reduction order: results are bit-reproducible.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x1, int ld1, int C1,
                                                        const float* __restrict__ x2, int ld2, int C2, int HW,
-                                                       int groups, float eps, float* __restrict__ stats) {
+                                                       int groups, float eps, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ tab) {
     __shared__ float red[4];
+    __shared__ float mr[2];
     const int C = C1 + C2, cpg = C / groups;
     const int b = blockIdx.x / groups, g = blockIdx.x - b * groups;
     const int tp_n = 256 / cpg;
@@ -106,38 +109,48 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     const float qm = block_sum((q0 + q1) + (q2 + q3), red) / n;
     if (threadIdx.x == 0) {
         const float var = fmaxf(qm - sm * sm, 0.f);
-        stats[2 * blockIdx.x] = pivot + sm;
-        stats[2 * blockIdx.x + 1] = 1.f / sqrtf(var + eps);
+        mr[0] = pivot + sm;
+        mr[1] = 1.f / sqrtf(var + eps);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < cpg) {
+        const int cc = c0 + threadIdx.x;
+        const float sc = gamma[cc] * mr[1];
+        tab[2 * ((long long)b * C + cc)] = sc;
+        tab[2 * ((long long)b * C + cc) + 1] = beta[cc] - mr[0] * sc;
     }
 }
 
-// GroupNorm pass 2: y = x*scale + shift (scale = gamma*rstd, shift = beta - mean*scale, as ATen) [+ SiLU], four
-// channels per thread, coalesced float4 in, fp32 or bf16-plane out
+// GroupNorm pass 2: y = x*scale + shift [+ SiLU].  Block = 16 rows of one sample x all channels, thread = (row lane,
+// channel-quad lane): the per-(sample, channel) scale/shift pair is fetched once per quad and reused down the rows;
+// 16 quad lanes = 256 contiguous bytes per row, fp32 or split32 out.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x1, int ld1, int C1,
-                                                       const float* __restrict__ x2, int ld2, int C2, long long rows,
-                                                       int HW, int groups, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const float* __restrict__ stats,
-                                                       int silu, float* __restrict__ out, int split) {
-    const int C = C1 + C2, cpg = C / groups, c4n = C / 4;
-    const long long total = rows * c4n;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long row = i / c4n;
-        const int c = (int)(i - row * c4n) * 4;
-        const int b = (int)(row / HW);
+                                                       const float* __restrict__ x2, int ld2, int C2, int HW,
+                                                       const float* __restrict__ tab, int silu,
+                                                       float* __restrict__ out, int split) {
+    const int C = C1 + C2, c4n = C >> 2;
+    const int b = blockIdx.y, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int r0 = blockIdx.x * 16 + ty;
+    if (r0 >= HW) return;
+    const long long row = (long long)b * HW + r0;
+    const float4* t4 = reinterpret_cast<const float4*>(tab + 2 * (long long)b * C);
+    for (int q = tx + 16 * blockIdx.z; q < c4n; q += 16 * gridDim.z) {      // grid.z splits the quads of small tensors
+        const int c = q * 4;
+        const float4 ta = t4[2 * q], tb = t4[2 * q + 1];      // {sc0, sh0, sc1, sh1}, {sc2, sh2, sc3, sh3}
         const float4 v = c < C1 ? *reinterpret_cast<const float4*>(x1 + row * ld1 + c)
                                 : *reinterpret_cast<const float4*>(x2 + row * ld2 + (c - C1));
-        const float in[4] = {v.x, v.y, v.z, v.w};
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int ce = c + e;
-            const float* st = stats + 2 * (b * groups + ce / cpg);
-            const float sc = gamma[ce] * st[1];
-            float y = in[e] * sc + (beta[ce] - st[0] * sc);
-            if (silu) y = y / (1.f + expf(-y));
-            o[e] = y;
+        float4 y;
+        y.x = v.x * ta.x + ta.y;
+        y.y = v.y * ta.z + ta.w;
+        y.z = v.z * tb.x + tb.y;
+        y.w = v.w * tb.z + tb.w;
+        if (silu) {
+            y.x = __fdividef(y.x, 1.f + __expf(-y.x));
+            y.y = __fdividef(y.y, 1.f + __expf(-y.y));
+            y.z = __fdividef(y.z, 1.f + __expf(-y.z));
+            y.w = __fdividef(y.w, 1.f + __expf(-y.w));
         }
-        store4(out, row, c, C, split, make_float4(o[0], o[1], o[2], o[3]));
+        store4(out, row, c, C, split, y);
     }
 }
 
@@ -242,18 +255,18 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
                       int groups, const float* gamma, const float* beta, float eps, int silu, float* out,
                       int out_split) {
     const int C = C1 + C2;
-    float* stats = ctx.ws.alloc_f((size_t)2 * B * groups);    // released with the caller's arena mark
+    float* tab = ctx.ws.alloc_f((size_t)2 * B * C);    // per-(sample, channel) {scale, shift}; released with the caller's arena mark
     if (ctx.ws.dry) return;
     MAA_CHECK(C % groups == 0 && C / groups <= 256 && C % 4 == 0 && C1 % 4 == 0 && ld1 % 4 == 0 && (C2 == 0 || ld2 % 4 == 0),
               "groupnorm channels");
     ProfScope prof(ctx, "groupnorm", 0.0, 8.0 * B * (double)HW * C);
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW, groups,
-                       eps, stats);
-    const long long rows = (long long)B * HW, total = rows * (C / 4);
-    long long blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx.stream, x1, ld1, C1, x2, ld2, C2, rows,
-                       HW, groups, gamma, beta, stats, silu, out, out_split);
+                       eps, gamma, beta, tab);
+    const int rb = (HW + 15) / 16, passes = (C / 4 + 15) / 16;
+    int nz = (768 + rb * B - 1) / (rb * B);         // aim at >= 3 workgroups per CU
+    nz = nz < 1 ? 1 : nz > passes ? passes : nz;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)rb, (unsigned)B, (unsigned)nz), dim3(256), 0, ctx.stream, x1, ld1,
+                       C1, x2, ld2, C2, HW, tab, silu, out, out_split);
     MAA_HIP(hipGetLastError());
 }
 

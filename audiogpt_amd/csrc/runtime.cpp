@@ -175,17 +175,19 @@ void WeightStore::finish(PackedW& pw, const std::vector<float>& kn, bool bf16_ok
         // pre-split "split32" rows [Npad][K]: every 32 k of a row are one 128-byte line [32 hi | 32 lo] with
         // hi = bf16(w), lo = bf16(w - hi); the kernel copies the lines straight to LDS.  ld is in fp32 units.
         MAA_CHECK(pw.K % 32 == 0, "split32 weights need K % 32 == 0");
-        std::vector<unsigned short> t((size_t)pw.Npad * pw.K * 2, 0);
+        static const int wpad = std::getenv("MAA_WPAD") ? std::atoi(std::getenv("MAA_WPAD")) : 0;   // experiment
+        const int ldk = pw.K + wpad;
+        std::vector<unsigned short> t((size_t)pw.Npad * ldk * 2, 0);
         for (int k = 0; k < pw.K; ++k)
             for (int n = 0; n < pw.Npad; ++n) {
                 const float w = kn[(size_t)k * pw.Npad + n];
                 const unsigned short hi = f2bf(w);
-                const size_t at = (size_t)n * pw.K * 2 + (size_t)(k >> 5) * 64 + (k & 31);
+                const size_t at = (size_t)n * ldk * 2 + (size_t)(k >> 5) * 64 + (k & 31);
                 t[at] = hi;
                 t[at + 32] = f2bf(w - bf2f(hi));
             }
         pw.w = static_cast<float*>(upload_raw(t.data(), t.size() * sizeof(unsigned short)));
-        pw.ld = pw.K;
+        pw.ld = ldk;
         pw.nk = 1;
         pw.split = 1;
         pw.lo_off = 0;

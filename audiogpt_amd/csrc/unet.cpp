@@ -14,6 +14,7 @@
 #include "models.h"
 
 #include <cmath>
+#include <cstdlib>
 
 namespace maa {
 
@@ -309,6 +310,11 @@ struct UNet::Impl {
         float* y = ctx.ws.alloc_f((size_t)M * inner);
         linear_into(ctx, xn, s.ch, M, s.ch, s.proj_in, nullptr, 0, y, inner, 0, 0, sp_in ? M : 0);
         const float scale = 1.0f / std::sqrt((float)s.dh);
+        // attention outputs and the GEGLU product feed exactly one projection each: in the bf16 modes they are written
+        // as split32 rows, so to_out / ff.net.2 take the LDS-DMA engine with no per-tile conversion
+        static const bool no_osplit = std::getenv("MAA_NO_OSPLIT") != nullptr;      // A/B timing only
+        const int o_sp = !no_osplit && sp && flash_attention_covers(ctx, s.dh) ? 1 : 0;
+        const int g_sp = !no_osplit && split_for_gemm(ctx, 4 * inner) ? 1 : 0;
         for (const STBlockW& b : s.blocks) {
             float* ln = ctx.ws.alloc_f((size_t)M * inner);
             float* o = ctx.ws.alloc_f((size_t)M * inner);
@@ -317,9 +323,9 @@ struct UNet::Impl {
             float* qkv = ctx.ws.alloc_f((size_t)M * 3 * inner);
             linear_into(ctx, ln, inner, M, inner, b.qkv1, nullptr, 0, qkv, 3 * inner, 0, 0, sp ? M : 0);
             attention_into(ctx, qkv, 3 * inner, s.dh, qkv + inner, 3 * inner, s.dh, qkv + 2 * inner, 3 * inner, s.dh,
-                           B, s.heads, s.dh, HW, HW, scale, o, inner);
+                           B, s.heads, s.dh, HW, HW, scale, o, inner, o_sp);
             float* y1 = ctx.ws.alloc_f((size_t)M * inner);
-            linear_into(ctx, o, inner, M, inner, b.out1, y, inner, y1, inner);
+            linear_into(ctx, o, inner, M, inner, b.out1, y, inner, y1, inner, 0, 0, o_sp ? M : 0);
             // x = attn2(norm2(x), context) + x      (:213)
             launch_layernorm(ctx, y1, M, inner, b.ln2g, b.ln2b, 1e-5f, ln, sp);
             float* q = ctx.ws.alloc_f((size_t)M * inner);
@@ -327,15 +333,15 @@ struct UNet::Impl {
             MAA_CHECK(ctx.ws.dry || (kv_cache[b.kv_slot] && kv_batch == B), "set_context must precede forward (batch)");
             const float* kv = kv_cache[b.kv_slot];
             attention_into(ctx, q, inner, s.dh, kv, 2 * inner, s.dh, kv + inner, 2 * inner, s.dh, B, s.heads, s.dh, HW,
-                           kv_len, scale, o, inner);
+                           kv_len, scale, o, inner, o_sp);
             float* y2 = ctx.ws.alloc_f((size_t)M * inner);
-            linear_into(ctx, o, inner, M, inner, b.out2, y1, inner, y2, inner);
+            linear_into(ctx, o, inner, M, inner, b.out2, y1, inner, y2, inner, 0, 0, o_sp ? M : 0);
             // x = ff(norm3(x)) + x      (:214)
             launch_layernorm(ctx, y2, M, inner, b.ln3g, b.ln3b, 1e-5f, ln, sp);
             float* g = ctx.ws.alloc_f((size_t)M * 4 * inner);
-            linear_into(ctx, ln, inner, M, inner, b.ff1, nullptr, 0, g, 4 * inner, /*geglu=*/1, 0, sp ? M : 0);
+            linear_into(ctx, ln, inner, M, inner, b.ff1, nullptr, 0, g, 4 * inner, /*geglu=*/1, 0, sp ? M : 0, g_sp);
             float* y3 = ctx.ws.alloc_f((size_t)M * inner);
-            linear_into(ctx, g, 4 * inner, M, 4 * inner, b.ff2, y2, inner, y3, inner);
+            linear_into(ctx, g, 4 * inner, M, 4 * inner, b.ff2, y2, inner, y3, inner, 0, 0, g_sp ? M : 0);
             y = y3;
         }
         linear_into(ctx, y, inner, M, inner, s.proj_out, x.p, s.ch, out.p, s.ch);

@@ -160,3 +160,41 @@ def test_batch_invariance(golden, ctx):
     y1 = unet(x[1:2], t[1:2], c[1:2]).cpu()
     unet.close()
     assert torch.equal(yb[1:2], y1) and torch.equal(yb[2:3], y1)
+
+
+_DMA_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+from audiogpt_amd import config as C, weights as WT
+from audiogpt_amd.backend import Context, UNet
+g = np.load({golden!r})
+ctx = Context("cuda:0", precision="bf16x3")
+unet = UNet(ctx, C.UNET_T2A, WT.make_unet_state_dict(C.UNET_T2A, seed=0))
+y = unet(torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"])).cpu().numpy()
+np.save({out!r}, y)
+"""
+
+
+def test_dma_engine_bit_identical(tmp_path):
+    """The LDS-DMA implicit-GEMM engine (igemm_dma.hip) and the register-staged one (MAA_NO_DMA=1) run the same
+    arithmetic in the same order: a whole UNet forward (every conv / linear shape, strides, upsampling, GEGLU) must
+    agree bit for bit -- any mis-addressed tile row, swizzle slip or copy/read race shows up here."""
+    import os
+    import subprocess
+    import sys
+
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = os.path.join(root, "tests", "golden", "unet_t2a.npz")
+    outs = []
+    for tag, env in (("dma", {}), ("reg", {"MAA_NO_DMA": "1"})):
+        out = str(tmp_path / f"y_{tag}.npy")
+        e = dict(os.environ)
+        e.pop("MAA_NO_DMA", None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", _DMA_SCRIPT.format(root=root, golden=golden, out=out)], env=e,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all()
+    assert np.array_equal(outs[0], outs[1]), float(np.abs(outs[0] - outs[1]).max())
