@@ -21,6 +21,7 @@
 // both engines return bit-identical results; MAA_NO_DMA=1 routes everything through the register kernel (tests).
 #include "igemm_epilogue.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace maa {
@@ -252,25 +253,35 @@ int igemm_dma_tile(const IGemm& p, int cfg) {
 }
 
 void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
-    static const int ns_env = std::getenv("MAA_DMA_NS") ? std::atoi(std::getenv("MAA_DMA_NS")) : 0;    // tuning
+    static int ns_cfg[3] = {0, 0, 0};           // tuning: MAA_DMA_NS="n" (all tiles) or "n0,n1,n2" (128x128, 128x64, 64x64)
+    static const bool ns_parsed = [] {
+        if (const char* e = std::getenv("MAA_DMA_NS")) {
+            const int k = std::sscanf(e, "%d,%d,%d", &ns_cfg[0], &ns_cfg[1], &ns_cfg[2]);
+            if (k == 1) ns_cfg[1] = ns_cfg[2] = ns_cfg[0];
+        }
+        return true;
+    }();
+    (void)ns_parsed;
+    const int ns_env = ns_cfg[cfg];
     const long long ncols = (long long)p.N * (p.geglu ? 2 : 1);
     // LDS stages: inside the UNet the weights of every layer come cold from HBM (each layer's weights are 3-4x an
     // XCD's L2 and the whole model streams through once per DDIM step), so the deeper copy queue wins there even
     // though the L2-warm micro-benchmark prefers more workgroups per CU: 64x64 -> 4 stages (64 KB, 2 workgroups/CU),
-    // 128x64 -> 3 (72 KB, 2/CU), 128x128 -> 2 (64 KB, 2/CU).   (in-pipeline A/B: profiles/r1_bf16x3_dma_sweep.txt)
+    // 128x64 -> 3 (72 KB, 2/CU), 128x128 -> 2 (64 KB, 2/CU).  In-pipeline A/B (20 DDIM steps + decode, ms): stages
+    // (128x128, 128x64, 64x64) = (2,3,4) 234.0 | (2,2,2) +3.7 % | (2,3,5) +0.9 % | (2,3,6) +18.6 % | (2,4,4) +7.5 % | (3,3,4) +3.8 %.
     const int ns = ns_env ? ns_env : (cfg == 2 ? 4 : cfg == 1 ? 3 : 2);
     (void)ncols;
     switch (cfg) {
         case 0:
-            if (ns == 3) launch_one<128, 128, 2, 2, 3>(ctx, p, Nb);
+            if (ns >= 3) launch_one<128, 128, 2, 2, 3>(ctx, p, Nb);
             else launch_one<128, 128, 2, 2, 2>(ctx, p, Nb);
             break;
         case 1:
-            if (ns == 3) launch_one<128, 64, 2, 2, 3>(ctx, p, Nb);
+            if (ns >= 3) launch_one<128, 64, 2, 2, 3>(ctx, p, Nb);
             else launch_one<128, 64, 2, 2, 2>(ctx, p, Nb);
             break;
         default:
-            if (ns == 4) launch_one<64, 64, 2, 2, 4>(ctx, p, Nb);
+            if (ns >= 4) launch_one<64, 64, 2, 2, 4>(ctx, p, Nb);
             else if (ns == 3) launch_one<64, 64, 2, 2, 3>(ctx, p, Nb);
             else launch_one<64, 64, 2, 2, 2>(ctx, p, Nb);
             break;
