@@ -86,7 +86,15 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
         const int nblk = gridDim.x, xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
         bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     }
-    const int nt = bid % ntiles, mt = bid / ntiles;
+    int nt, mt;
+    if (p.m_fastest) {             // an XCD's contiguous range = all M-tiles of a few N-tiles: weights fetched once chip-wide
+        const int mtiles = gridDim.x / ntiles;
+        mt = bid % mtiles;
+        nt = bid / mtiles;
+    } else {
+        nt = bid % ntiles;
+        mt = bid / ntiles;
+    }
     const int m0 = mt * BM, n0 = nt * BN;
     const int z = blockIdx.y;
     const int zo = z / p.zin, zi = z - zo * p.zin;
@@ -413,8 +421,10 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     }
     ProfScope prof(ctx, pname, flops, bytes);
     static const int dbg = std::getenv("MAA_DBG") ? std::atoi(std::getenv("MAA_DBG")) : 0;   // ablation runs only
+    static const int m_fastest = std::getenv("MAA_TILE_ORDER") ? std::atoi(std::getenv("MAA_TILE_ORDER")) : 0;
     IGemm q = p;
     q.dbg = dbg;
+    q.m_fastest = m_fastest && p.Z == 1;
     if (dma)
         launch_igemm_dma(ctx, q, cfg, Nb);
     else if (terms == 3)

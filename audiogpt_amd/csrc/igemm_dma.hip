@@ -60,7 +60,15 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const IGemm p, int ntiles
         const int nblk = gridDim.x, xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
         bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
     }
-    const int nt = bid % ntiles, mt = bid / ntiles;
+    int nt, mt;
+    if (p.m_fastest) {             // an XCD's contiguous range = all M-tiles of a few N-tiles: weights fetched once chip-wide
+        const int mtiles = gridDim.x / ntiles;
+        mt = bid % mtiles;
+        nt = bid / mtiles;
+    } else {
+        nt = bid % ntiles;
+        mt = bid / ntiles;
+    }
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int Ctot = p.C1;                     // single split32 source (checked by the launcher)

@@ -132,6 +132,8 @@ struct IGemm {
     float* c = nullptr;
     int ldc = 0;
     const float* zeros = nullptr;    // >= 16 B of zeros in device memory (filled in by launch_igemm)
+    int m_fastest = 0;               // tile order inside an XCD's range: 1 = M-tiles fastest (MAA_TILE_ORDER=1: weights are
+                                     // then fetched once chip-wide, but the conv's A re-reads lose their L2: +4 % step time)
     int dbg = 0;                     // timing ablations (MAA_DBG): 1 skip MFMA phase, 2 skip tile loads, 4 skip LDS stores (DMA engine: barrier), 8 skip the DMA wait
 };
 void launch_igemm(const Ctx& ctx, const IGemm& p);
