@@ -17,8 +17,10 @@ for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
   python scripts/pmc_summary.py gpurun_out/pmc_${tag}_$n/pmc_results.db 14 | grep -v "^# columns" >> gpurun_out/prof_${tag}_pmc.txt 2>&1
   rm -rf gpurun_out/pmc_${tag}_$n gpurun_out/pmc_${tag}_$n.log
 done
+# HBM-side bytes per launch of the dominant kernel family -> read by bench.py for roofline.traffic
+python scripts/pmc_traffic_json.py gpurun_out/prof_${tag}_pmc.txt "igemm_dma_kernel<64, 64" igemm_dma_bf16x3 $prec profiles/r1_pmc_traffic.json && cp profiles/r1_pmc_traffic.json gpurun_out/pmc_traffic_$tag.json
 python bench.py --steps 3 --warmup 1 --precision $prec > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
 python -c "
-import json; d=json.load(open('gpurun_out/bench_$tag.json')); print('VALUE', d['value'], d['ms_per_step']); r=d['roofline']; print({k:r[k] for k in ('kernel','achieved','peak','frac','avg_launch_us','launches')}); print(d['cpu_baseline'])"
+import json; d=json.load(open('gpurun_out/bench_$tag.json')); print('VALUE', d['value'], d['ms_per_step']); r=d['roofline']; print({k:r[k] for k in ('kernel','achieved','peak','frac','avg_launch_us','launches','traffic')}); print(d['cpu_baseline'])"
 head -12 gpurun_out/prof_${tag}_kernel_stats.txt | cut -c1-175
 cat gpurun_out/prof_${tag}_pmc.txt | cut -c1-220
