@@ -315,6 +315,7 @@ struct UNet::Impl {
         static const bool no_osplit = std::getenv("MAA_NO_OSPLIT") != nullptr;      // A/B timing only
         const int o_sp = !no_osplit && sp && flash_attention_covers(ctx, s.dh) ? 1 : 0;
         const int g_sp = !no_osplit && split_for_gemm(ctx, 4 * inner) ? 1 : 0;
+        int y_sp = 0;
         for (const STBlockW& b : s.blocks) {
             float* ln = ctx.ws.alloc_f((size_t)M * inner);
             float* o = ctx.ws.alloc_f((size_t)M * inner);
@@ -341,10 +342,14 @@ struct UNet::Impl {
             float* g = ctx.ws.alloc_f((size_t)M * 4 * inner);
             linear_into(ctx, ln, inner, M, inner, b.ff1, nullptr, 0, g, 4 * inner, /*geglu=*/1, 0, sp ? M : 0, g_sp);
             float* y3 = ctx.ws.alloc_f((size_t)M * inner);
-            linear_into(ctx, g, 4 * inner, M, 4 * inner, b.ff2, y2, inner, y3, inner, 0, 0, g_sp ? M : 0);
+            // the last block's output feeds only proj_out: written as split32 as well (bias + residual are applied
+            // before the split, in the same epilogue)
+            const bool last = &b == &s.blocks.back();
+            y_sp = last && sp && !no_osplit ? 1 : 0;
+            linear_into(ctx, g, 4 * inner, M, 4 * inner, b.ff2, y2, inner, y3, inner, 0, 0, g_sp ? M : 0, y_sp);
             y = y3;
         }
-        linear_into(ctx, y, inner, M, inner, s.proj_out, x.p, s.ch, out.p, s.ch);
+        linear_into(ctx, y, inner, M, inner, s.proj_out, x.p, s.ch, out.p, s.ch, 0, 0, y_sp ? M : 0);
         ctx.ws.release(mk);
         return out;
     }
