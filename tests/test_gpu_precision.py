@@ -198,3 +198,86 @@ def test_dma_engine_bit_identical(tmp_path):
         outs.append(np.load(out))
     assert np.isfinite(outs[0]).all()
     assert np.array_equal(outs[0], outs[1]), float(np.abs(outs[0] - outs[1]).max())
+
+
+# ---- the other models of the path in the benchmark mode (bf16x3), against the same reference goldens and gates as the
+# ---- exact-fp32 tests in tests/test_gpu_models.py
+@pytest.fixture(scope="module")
+def ctx3():
+    from audiogpt_amd.backend import Context
+    c = Context("cuda:0", precision="bf16x3")
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name,cfg,seed", [("unet_i2a", C.UNET_I2A, 4), ("unet_inpaint", C.UNET_INPAINT, 5)])
+def test_bf16x3_unet_variants_match_reference(golden, ctx3, name, cfg, seed):
+    from audiogpt_amd.backend import UNet
+    gg = golden(name)
+    u = UNet(ctx3, cfg, WT.make_unet_state_dict(cfg, seed=seed))
+    c = torch.from_numpy(gg["context"]) if "context" in gg else None
+    y = u(torch.from_numpy(gg["x"]), torch.from_numpy(gg["t"]), c)
+    check("bf16x3_" + name + "_vs_reference", y, gg["y"], 1e-4)
+    u.close()
+
+
+def test_bf16x3_vae_decode_and_encode_match_reference(golden, ctx3):
+    from audiogpt_amd.backend import VAE
+    gg = golden("vae")
+    vae = VAE(ctx3, C.VAE_DDCONFIG, WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1))
+    mel = vae.decode(torch.from_numpy(gg["z"]), 1.0)
+    check("bf16x3_vae_decode_vs_reference", mel, gg["mel"], 2e-4)
+    m01 = torch.clamp((mel.cpu() + 1) / 2, 0, 1)
+    r01 = torch.clamp((torch.from_numpy(gg["mel"]) + 1) / 2, 0, 1)
+    l1 = float((m01 - r01).abs().mean())
+    record("bf16x3_vae_mel_l1", mel_l1=l1, tol=1e-4)
+    assert l1 <= 1e-4
+    mom = vae.encode_moments(torch.from_numpy(gg["mel_in"]))
+    check("bf16x3_vae_encode_vs_reference", mom, gg["moments"], 2e-4)
+    vae.close()
+
+
+@pytest.mark.parametrize("name,cfg,seed,tol", [("hifigan_16k_t2a", C.HIFIGAN_16K, 2, 2e-4), ("hifigan_ns512", C.HIFIGAN_NS_512, 2, 2e-4),
+                                               ("hifigan_ns128", C.HIFIGAN_NS_128, 2, 2e-4), ("bigvgan_16k", C.BIGVGAN_16K, 3, 5e-4)])
+def test_bf16x3_vocoders_match_reference(golden, ctx3, name, cfg, seed, tol):
+    from audiogpt_amd.backend import Vocoder
+    gg = golden(name)
+    v = Vocoder(ctx3, cfg, WT.make_vocoder_state_dict(cfg, seed=seed))
+    wav = v(torch.from_numpy(gg["mel"])).cpu()
+    ref = torch.from_numpy(gg["wav"])
+    rms = float(((wav - ref) ** 2).mean().sqrt())
+    record("bf16x3_" + name + "_wav_rms", wav_rms=rms, tol=1e-4)
+    check("bf16x3_" + name + "_vs_reference", wav, ref, tol)
+    assert rms <= 1e-4
+    v.close()
+
+
+def test_bf16x3_vocoder_ragged_lengths_and_batch_rows(ctx3):
+    """Edge cases in the benchmark mode: T not a multiple of any tile (1, 7, 33 frames), batch rows independent."""
+    from audiogpt_amd.backend import Vocoder
+    from oracle import vocoder as O
+    cfg = C.HIFIGAN_NS_128
+    sd = WT.make_vocoder_state_dict(cfg, seed=2)
+    v = Vocoder(ctx3, cfg, sd)
+    gen = torch.Generator().manual_seed(11)
+    for T in (1, 7, 33):
+        mel = torch.randn(3, 80, T, generator=gen)
+        wav = v(mel).cpu()
+        with torch.no_grad():
+            ref = O.hifigan_forward(O.fold_weight_norm(sd), cfg, mel)
+        check(f"bf16x3_hifigan_T{T}", wav, ref, 2e-4)
+        one = v(mel[2:3]).cpu()
+        assert torch.equal(one, wav[2:3])
+    v.close()
+
+
+def test_bf16x3_ddim_graph_replay_is_bit_identical(golden, ctx3):
+    from audiogpt_amd.backend import UNet
+    gd = golden("ddim_t2a_s10")
+    unet = UNet(ctx3, C.UNET_T2A, WT.make_unet_state_dict(C.UNET_T2A, seed=0))
+    steps, a, ap = _tables(6)
+    args = dict(cond=torch.from_numpy(gd["c"]), uncond=torch.from_numpy(gd["uc"]), scale=1.5)
+    z0 = unet.ddim_sample(torch.from_numpy(gd["x_T"]), steps, a, ap, use_graph=False, **args).cpu()
+    z1 = unet.ddim_sample(torch.from_numpy(gd["x_T"]), steps, a, ap, use_graph=True, **args).cpu()
+    unet.close()
+    assert torch.equal(z0, z1)
