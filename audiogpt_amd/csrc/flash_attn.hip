@@ -16,6 +16,8 @@
 // O^T is transposed through LDS at the end so that the output rows are written as contiguous runs of d.
 #include "maa_internal.h"
 
+#include <cstdlib>
+
 namespace maa {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -33,6 +35,7 @@ struct FlashArgs {
     float* out;
     int ldo;
     int out_split;                // write split32 lines (the to_out projection reads them with no conversion)
+    int precise_exp;              // MAA_FLASH_PRECISE_EXP=1: libm expf instead of v_exp_f32 (A/B timing)
     long long o_bs;
     const float* zeros;
 };
@@ -211,20 +214,37 @@ __global__ __launch_bounds__(NT) void flash_attn_kernel(const FlashArgs a) {
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = expf(m_run - m_new);          // first tile: exp(-inf) = 0
-        float ls = 0.f;
+        // exp through v_exp_f32 (exp2 of a pre-scaled argument, ~1 ulp): the softmax is the VALU-heavy part of this
+        // kernel; the running maximum settles after the first tiles, so the rescale of O is skipped for a wave whose
+        // lanes all kept their maximum (alpha == 1 exactly)
+        float alpha, ls = 0.f;
+        if (a.precise_exp) {
+            alpha = expf(m_run - m_new);                  // first tile: exp(-inf) = 0
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            p[r] = expf(p[r] - m_new);                    // masked keys: exp(-inf) = 0
-            ls += p[r];
+            for (int r = 0; r < 16; ++r) {
+                p[r] = expf(p[r] - m_new);                // masked keys: exp(-inf) = 0
+                ls += p[r];
+            }
+        } else {
+            constexpr float L2E = 1.4426950408889634f;
+            const float mb2 = m_new * L2E;
+            alpha = __builtin_amdgcn_exp2f(m_run * L2E - mb2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(p[r] * L2E - mb2);
+                ls += p[r];
+            }
         }
         ls += __shfl_xor(ls, 32, 64);
         l_run = l_run * alpha + ls;
+        const bool moved = m_new != m_run;
         m_run = m_new;
+        if (__any(moved)) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[mb][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[mb][r] *= alpha;
+        }
 
         // ---- O^T += V^T . P^T ; k-slot (lh*8 + t) of step u  <->  key 16u + 4 lh + (t&3) + 8 (t>>2)  <->  p[8u + t]
 #pragma unroll
@@ -347,6 +367,8 @@ bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, co
     a.out = out;
     a.ldo = ldo;
     a.out_split = out_split;
+    static const int precise_exp = std::getenv("MAA_FLASH_PRECISE_EXP") ? 1 : 0;
+    a.precise_exp = precise_exp;
     a.o_bs = (long long)Nq * ldo;
     a.zeros = ctx.zeros;
     const double flops = 4.0 * B * heads * (double)Nq * Nk * dh;
