@@ -8,9 +8,13 @@
 //              per 16-deep k-step: 16/3 = 5.3x the fp32 MFMA rate (gfx950 has no TF32/xf32, and its fp32 MFMA runs
 //              at 1/16 of the bf16 rate, so this is the fast path that still meets the fp32 parity gates).
 //   TERMS = 1  plain bf16 operands (throughput mode; error reported, not gated at 1e-4).
-// LDS tiles are row-major with k contiguous ([m][32 k] bf16, row pitch 40 = 80 B, which makes the 16-lane groups of
-// ds_read_b128 hit 16 distinct 16-byte slots): a lane's MFMA operand (8 consecutive k of one row) is one
-// ds_read_b128.  B must be given k-contiguous ([N][K]: packed weights in this mode, and K of Q.K^T).
+// LDS tiles are row-major with k contiguous: [row][32 k] bf16 = 64-byte rows, no padding, one plane for hi and one
+// for lo; the four 16-byte slots of a row are XOR-swizzled by (row >> 2) & 3, so a lane's MFMA operand (8 consecutive
+// k of one row) is one conflict-free ds_read_b128.  B must be given k-contiguous ([N][K]: packed weights in this
+// mode, and K of Q.K^T).
+// This is the REGISTER-STAGED engine (global -> VGPR -> LDS): it takes fp32 operands (split on the fly while the tile
+// is written to LDS) and split32 operands alike.  Problems whose operands are BOTH split32 go to the LDS-DMA engine
+// (igemm_dma.hip) in the bf16x3 mode; the two engines issue the same products in the same order.
 #include "igemm_epilogue.h"
 
 #include <cstdlib>
