@@ -1,0 +1,123 @@
+"""Host-side logic of the drop-in layer, checked on CPU (no GPU, no compute calls into the library):
+schedules, weight folding, the vocoder registry, "no CPU fallback", and that the product never imports the oracle."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from audiogpt_amd import config as C
+from audiogpt_amd import weights as WT
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("ldm", [C.LDM_T2A, C.LDM_INPAINT], ids=["t2a", "inpaint"])
+@pytest.mark.parametrize("S", [10, 100, 4])
+def test_ddim_schedule_matches_oracle(ldm, S):
+    """pipeline.ddim_schedule (what the C loop is driven by) == the oracle's restatement of ddim.py:27-56 / util.py:46-74."""
+    from audiogpt_amd.pipeline import alphas_cumprod_f32, ddim_schedule
+    from oracle import ddim as O
+    ac = alphas_cumprod_f32(ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+    ac_o = O.alphas_cumprod(ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+    assert np.array_equal(ac, ac_o.numpy())
+    steps, a, ap = ddim_schedule(S, ac)
+    steps_o = O.ddim_timesteps(S, ldm["timesteps"])
+    a_o, ap_o, sg, _ = O.ddim_tables(ac_o, steps_o)
+    assert steps.tolist() == steps_o.tolist() and steps[0] == 1 and steps.max() < ldm["timesteps"]
+    assert np.array_equal(a, a_o.numpy()) and np.array_equal(ap, ap_o.numpy())
+    assert float(ap[0]) == float(ac[0])                       # a_prev[0] = alphas_cumprod[0], not 1 (util.py:63-69)
+    assert float(sg.abs().max()) == 0.0                       # eta = 0
+
+
+def test_fold_weight_norm_is_torch_remove_weight_norm():
+    """weights.fold_weight_norm == torch.nn.utils.weight_norm's w = g * v / ||v|| for Conv1d and ConvTranspose1d."""
+    g = torch.Generator().manual_seed(3)
+    for mod in (torch.nn.Conv1d(6, 10, 5), torch.nn.ConvTranspose1d(6, 10, 4, stride=2)):
+        m = torch.nn.utils.weight_norm(mod)
+        with torch.no_grad():
+            m.weight_g.copy_(torch.rand(m.weight_g.shape, generator=g) + 0.5)
+            m.weight_v.copy_(torch.randn(m.weight_v.shape, generator=g))
+        sd = {"c.weight_g": m.weight_g.detach().clone(), "c.weight_v": m.weight_v.detach().clone(),
+              "c.bias": m.bias.detach().clone()}
+        ref = torch.nn.utils.remove_weight_norm(m).weight.detach()
+        out = WT.fold_weight_norm(sd)
+        assert set(out) == {"c.weight", "c.bias"}
+        assert torch.allclose(out["c.weight"], ref, rtol=1e-6, atol=1e-7)
+
+
+def test_strip_prefix_selects_submodule():
+    sd = {"model.diffusion_model.a.weight": 1, "first_stage_model.b": 2, "scale_factor": 3}
+    assert WT.strip_prefix(sd, "model.diffusion_model.") == {"a.weight": 1}
+
+
+def test_vocoder_registry_mirrors_reference():
+    """NeuralSeq/vocoders/base_vocoder.py:1-19: registered short name, class name, or dotted path."""
+    from audiogpt_amd.vocoder import hifigan as V
+    assert V.get_vocoder_cls({"vocoder": "HifiGAN"}) is V.HifiGAN
+    assert V.get_vocoder_cls({"vocoder": "hifigan"}) is V.HifiGAN
+    assert V.get_vocoder_cls({"vocoder": "audiogpt_amd.vocoder.hifigan.HifiGAN"}) is V.HifiGAN
+
+    @V.register_vocoder
+    class Dummy(V.BaseVocoder):
+        pass
+    assert V.get_vocoder_cls({"vocoder": "dummy"}) is Dummy
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every product entry point raises: tools, pipeline and vocoders build a backend.Context first."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from audiogpt_amd import _lib
+    from audiogpt_amd.pipeline import MakeAnAudio
+    from audiogpt_amd.tools import T2A
+    from audiogpt_amd.vocoder.hifigan import HifiGanGenerator
+    for make in (lambda: MakeAnAudio("cuda:0"), lambda: T2A("cuda:0"),
+                 lambda: HifiGanGenerator(dict(C.HIFIGAN_NS_128), device="cuda:0")):
+        with pytest.raises((_lib.MaaError, AssertionError, RuntimeError)):
+            make()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under audiogpt_amd/ may import it (statically checked)."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "audiogpt_amd")):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.join(dirpath, f)
+            tree = ast.parse(open(path).read(), path)
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    bad.append(path)
+    assert not bad, bad
+
+
+def test_unet_layer_plan_matches_survey_counts():
+    """weights.unet_layers(T2A) reproduces the block map of SURVEY 8a/U1: 12 ResBlocks, 11 SpatialTransformers."""
+    layers = WT.unet_layers(C.UNET_T2A)
+    flat = []
+
+    def walk(x):
+        if isinstance(x, dict):
+            if "kind" in x:
+                flat.append(x["kind"])
+            for v in x.values():
+                walk(v)
+        elif isinstance(x, (list, tuple)):
+            for v in x:
+                walk(v)
+    walk(layers)
+    if flat:                                                   # plan exposes per-layer kinds
+        kinds = [str(k).lower() for k in flat]
+        assert sum("res" in k for k in kinds) == 12
+        assert sum(("st" == k) or ("transformer" in k) or ("spatial" in k) for k in kinds) == 11
+    sd = WT.make_unet_state_dict(C.UNET_T2A, seed=0)
+    n_params = sum(int(np.prod(v.shape)) for v in sd.values())
+    assert abs(n_params - 160.22e6) < 0.05e6                   # 160.2 M parameters
