@@ -428,7 +428,6 @@ int maa_op_conv_transpose1d(maa_ctx* ctx, const float* d_x, int B, int Cin, int 
                 p.ldb = pw.ld;
                 p.b_nk = pw.nk;
                 p.b_split = pw.split;
-                p.b_lo_off = pw.lo_off;
                 p.M = B * L;
                 p.K = U * Cin;
                 p.N = r_count * Cout;

@@ -30,7 +30,6 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
     p.ldb = w.ld;
     p.b_nk = w.nk;
     p.b_split = w.split;
-    p.b_lo_off = w.lo_off;
     if (x1.split) {
         MAA_CHECK(!x2, "a split source cannot be concatenated");
         p.a_split = 1;
@@ -70,7 +69,6 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
     p.ldb = w.ld;
     p.b_nk = w.nk;
     p.b_split = w.split;
-    p.b_lo_off = w.lo_off;
     if (a_split_rows > 0) {
         p.a_split = 1;
     }

@@ -379,7 +379,6 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     constexpr int BK = 32;      // channel granularity of the multi-tap gather (64-deep stages take two taps' worth)
     bool fast;
     if (p.a_split) {
-        // bf16 planes: 8-element (16-byte) pieces
         // split32 lines: whole 32-channel groups, rows pitched like their fp32 form
         fast = p.C2 == 0 && Ctot % 32 == 0 && p.lda1 % 32 == 0 && al16(p.a1) && p.Z == 1 && p.a_act == 0;
     } else {

@@ -102,16 +102,14 @@ struct IGemm {
     int Hin = 1, Win = 1, Hout = 1, Wout = 1;
     int KH = 1, KW = 1, sh = 1, sw = 1, ph = 0, pw = 0, dh = 1, dw = 1;
     int up = 0;                      // 1: source is read through a virtual nearest-2x upsample
-    int a_split = 0;                 // A is two bf16 planes (hi at a1, lo at +a_lo_off ushort elements); lda in ushorts
-    long long a_lo_off = 0;
+    int a_split = 0;                 // A rows are split32 lines ([32 bf16 hi | 32 bf16 lo] per 32 channels, pitch lda1 floats)
     int a_act = 0;                   // 0 none, 1 leaky-relu(a_slope)   (applied while staging an fp32 A)
     float a_slope = 0.f;
     // B operand
     const float* b = nullptr;
     int ldb = 0;
     int b_nk = 0;                    // 0: B stored [K][N] (packed weights, V);  1: stored [N][K] (K^T)
-    int b_split = 0;                 // B is two bf16 planes [N][K] (hi at b, lo at +b_lo_off); ldb in ushorts
-    long long b_lo_off = 0;
+    int b_split = 0;                 // B rows ([N][K]) are split32 lines, pitch ldb floats
     // dims
     int M = 0, N = 0, K = 0;
     // batching over blockIdx.z: z -> (zo, zi) = (z / zin, z % zin)
@@ -149,7 +147,7 @@ void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb);
 // ------------------------------------------------------------------------------------------ norms etc.
 // GroupNorm(32 groups) over a channels-last tensor given as a virtual concat of two sources; writes
 // a dense [B, HW, C1+C2] tensor.  silu: fuse x*sigmoid(x).
-// out_split = 1: the output is written as two bf16 planes (hi, then lo at +B*HW*C ushort elements) for a bf16-engine
+// out_split = 1: the output rows are written as split32 lines (see IGemm::a_split) for a bf16-engine
 // consumer instead of fp32 (same byte size).  Takes 2*B*C floats of scratch (per-sample channel scale/shift) from the arena.
 void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int B, int HW,
                       int groups, const float* gamma, const float* beta, float eps, int silu, float* out,
@@ -204,8 +202,7 @@ struct PackedW {
     float* bias = nullptr;  // [Npad] or null
     int K = 0, N = 0, Npad = 0;
     int ld = 0, nk = 0;
-    int split = 0;          // 1: w points to bf16 planes [2][Npad][ld] (hi, lo); lo plane at +lo_off ushorts
-    long long lo_off = 0;
+    int split = 0;          // 1: rows of w are split32 lines (row pitch ld floats)
 };
 
 class WeightStore {

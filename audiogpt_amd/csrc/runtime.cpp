@@ -190,7 +190,6 @@ void WeightStore::finish(PackedW& pw, const std::vector<float>& kn, bool bf16_ok
         pw.ld = ldk;
         pw.nk = 1;
         pw.split = 1;
-        pw.lo_off = 0;
         return;
     }
     if (!nk_) {

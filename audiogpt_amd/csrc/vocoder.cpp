@@ -215,7 +215,6 @@ struct Vocoder::Impl {
                 p.ldb = u.ph[gi].ld;
                 p.b_nk = u.ph[gi].nk;
                 p.b_split = u.ph[gi].split;
-                p.b_lo_off = u.ph[gi].lo_off;
                 p.M = B * L;
                 p.K = U * u.cin;
                 p.N = u.r_count[gi] * u.cout;
