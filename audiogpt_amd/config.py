@@ -79,6 +79,12 @@ HIFIGAN_16K = dict(           # MAA/vocoder/logs/hifi_0127/args.yml
 HIFIGAN_NS_512 = dict(HIFIGAN_16K, sampling_rate=22050)                    # egs_bases/tts/vocoder/hifigan.yaml
 HIFIGAN_NS_128 = dict(HIFIGAN_16K, sampling_rate=22050, upsample_initial_channel=128)  # configs/tts/hifigan.yaml
 
+# NSF (f0-conditioned) generator of the singing tools: checkpoints/0109_hifigan_bigpopcs_hop128 is not shipped, so the
+# rates are the hop-128 / 24 kHz factorisation assumed here (egs_bases/svs/popcs_ds_beta6.yaml:6-7,54-55,70); used by the
+# oracle groundwork for SURVEY 8f/N1 only.
+HIFIGAN_NSF_24K = dict(HIFIGAN_16K, sampling_rate=24000, upsample_rates=(8, 4, 2, 2), upsample_kernel_sizes=(16, 8, 4, 4),
+                       use_pitch_embed=True)
+
 # BigVGAN's args.yml (vocoder/logs/bigv16k53w) does not ship with the reference
 # (SURVEY.md section 0.3); these are the generator defaults it is exercised with here.
 BIGVGAN_16K = dict(

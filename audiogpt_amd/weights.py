@@ -291,6 +291,22 @@ def make_vocoder_state_dict(cfg, seed=2):
             sd["activation_post.act.beta"] = g.normal((ch,), 0.3)
     _wn(sd, g, "conv_post", (1, ch, 7), gain=0.3)
     sd["conv_post.bias"] = g.bias(1)
+    if cfg.get("use_pitch_embed"):
+        # NSF branch (hifigan.py:111-132): harmonic merge Linear(9 -> 1) and one plain Conv1d per stage
+        sd["m_source.l_linear.weight"] = g.normal((1, 9), 0.6)
+        sd["m_source.l_linear.bias"] = g.bias(1)
+        rates = cfg["upsample_rates"]
+        for i in range(len(rates)):
+            c_cur = uic // 2 ** (i + 1)
+            if i + 1 < len(rates):
+                s_f0 = 1
+                for r in rates[i + 1:]:
+                    s_f0 *= r
+                kk = 2 * s_f0
+            else:
+                kk = 1
+            sd[f"noise_convs.{i}.weight"] = g.normal((c_cur, 1, kk), 1.0 / math.sqrt(kk))
+            sd[f"noise_convs.{i}.bias"] = g.bias(c_cur)
     return sd
 
 

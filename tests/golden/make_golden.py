@@ -13,6 +13,7 @@ Import shims: `omegaconf` stub (bigvgan/models.py:17, op
 `scipy.signal.kaiser` shim and a `utils.hparams` stub for NeuralSeq's hifigan.py import chain.
 """
 import json
+import math
 import os
 import sys
 import types
@@ -196,6 +197,45 @@ def hifigan_case(name, cfg, T, manifest, B=1, seed=2, mel=None):
     return wav
 
 
+def hifigan_nsf_case(name, cfg, T, manifest, B=2, seed=6):
+    """NeuralSeq HifiGanGenerator with use_pitch_embed (the real SineGen / SourceModuleHnNSF of source.py), f0 given."""
+    import importlib.util
+    for n in ("modules", "modules.parallel_wavegan", "modules.parallel_wavegan.layers", "modules.parallel_wavegan.models"):
+        if n not in sys.modules:
+            sys.modules[n] = types.ModuleType(n)
+    sys.modules["modules.parallel_wavegan.layers"].UpsampleNetwork = object
+    sys.modules["modules.parallel_wavegan.layers"].ConvInUpsampleNetwork = object
+    sp = importlib.util.spec_from_file_location("modules.parallel_wavegan.models.source",
+                                                os.path.join(NS, "modules/parallel_wavegan/models/source.py"))
+    src = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(src)
+    sys.modules["modules.parallel_wavegan.models.source"] = src
+    sp2 = importlib.util.spec_from_file_location("ns_hifigan_nsf", os.path.join(NS, "modules/hifigan/hifigan.py"))
+    mod = importlib.util.module_from_spec(sp2)
+    sp2.loader.exec_module(mod)
+    h = {k: (list(map(list, v)) if k == "resblock_dilation_sizes" else (list(v) if isinstance(v, tuple) else v))
+         for k, v in cfg.items()}
+    h["audio_sample_rate"] = cfg["sampling_rate"]
+    gen = mod.HifiGanGenerator(h).eval()
+    manifest[name + ".ns"] = _manifest(gen)
+    sd = WT.make_vocoder_state_dict(cfg, seed=seed)
+    gen.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(9)
+    mel = torch.clamp(torch.randn(B, 80, T, generator=g) * 1.5 - 2.25, -6.0, 1.5)
+    # a voiced / unvoiced f0 contour: 110-440 Hz glides with unvoiced gaps
+    t = torch.arange(T, dtype=torch.float32)
+    f0 = torch.stack([220.0 * 2 ** (0.5 * torch.sin(2 * math.pi * t / (37.0 + 11 * b))) for b in range(B)])
+    f0[:, T // 5: T // 4] = 0.0
+    f0[1, -T // 6:] = 0.0
+    torch.manual_seed(4321)                   # the oracle re-draws rand_ini / noise from this seed in the same order
+    with torch.no_grad():
+        wav = gen(mel, f0)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), mel=mel.numpy(), f0=f0.numpy(), wav=wav.numpy(),
+                        noise_seed=np.int64(4321))
+    print(name, "wav std", float(wav.std()), "absmax", float(wav.abs().max()))
+    return wav
+
+
 def bigvgan_case(name, cfg, T, manifest, seed=3):
     from argparse import Namespace
     from vocoder.bigvgan.models import BigVGAN
@@ -230,10 +270,23 @@ def main():
     hifigan_case("hifigan_ns512", C.HIFIGAN_NS_512, 64, manifest, B=2)
     hifigan_case("hifigan_ns128", C.HIFIGAN_NS_128, 96, manifest, B=2)
     bigvgan_case("bigvgan_16k", C.BIGVGAN_16K, 48, manifest)
+    hifigan_nsf_case("hifigan_nsf_24k", C.HIFIGAN_NSF_24K, 40, manifest)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    print("torch", torch.__version__)
+
+
+def main_nsf_only():
+    """`python tests/golden/make_golden.py nsf`: add the NSF case without regenerating the other fixtures."""
+    torch.set_num_threads(8)
+    _install_shims()
+    with open(os.path.join(HERE, "manifest.json")) as f:
+        manifest = json.load(f)
+    hifigan_nsf_case("hifigan_nsf_24k", C.HIFIGAN_NSF_24K, 40, manifest)
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     print("torch", torch.__version__)
 
 
 if __name__ == "__main__":
-    main()
+    main_nsf_only() if sys.argv[1:] == ["nsf"] else main()

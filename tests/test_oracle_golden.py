@@ -125,3 +125,26 @@ def test_weight_factory_has_no_dead_tensors():
                WT.make_vocoder_state_dict(C.HIFIGAN_16K)):
         for k, v in sd.items():
             assert float(v.abs().max()) > 0, k
+
+
+def test_hifigan_nsf_branch_matches_reference(golden):
+    """Groundwork for SURVEY 8f/N1: the f0-conditioned (NSF) generator restated in oracle/nsf.py against the reference's
+    HifiGanGenerator(use_pitch_embed) + SourceModuleHnNSF, the two random draws of SineGen re-drawn from the same seed."""
+    from oracle import nsf as N
+    g = golden("hifigan_nsf_24k")
+    cfg = C.HIFIGAN_NSF_24K
+    sd = O_voc.fold_weight_norm(WT.make_vocoder_state_dict(cfg, seed=6))
+    mel, f0 = torch.from_numpy(g["mel"]), torch.from_numpy(g["f0"])
+    hop = int(np.prod(cfg["upsample_rates"]))
+    rand_ini, noise = N.draw_source_noise(int(g["noise_seed"]), mel.shape[0], mel.shape[2] * hop)
+    with torch.no_grad():
+        wav = N.hifigan_nsf_forward(sd, cfg, mel, f0, rand_ini, noise)
+    ref = torch.from_numpy(g["wav"])
+    assert wav.shape == ref.shape == (2, 1, 40 * 128)
+    err = float((wav - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-6, err
+    # the harmonic source is f0-driven: with f0 = 0 everywhere it degenerates to tanh(Linear(noise * sine_amp / 3))
+    har0 = N.harmonic_source(sd, torch.zeros_like(f0), hop, cfg["sampling_rate"], rand_ini, noise)
+    exp0 = torch.tanh(torch.nn.functional.linear(noise * (N.SINE_AMP / 3), sd["m_source.l_linear.weight"],
+                                                 sd["m_source.l_linear.bias"])).transpose(1, 2)
+    assert torch.allclose(har0, exp0, atol=1e-7)
