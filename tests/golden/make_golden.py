@@ -72,7 +72,7 @@ def _cond(n, L, seed):
     return torch.nn.functional.layer_norm(c, (1024,))
 
 
-def unet_case(name, cfg, H, W, ctx_len, manifest, n=2, seed=0):
+def unet_case(name, cfg, H, W, ctx_len, manifest, n=2, seed=0, save=True):
     if cfg["variant"] == "i2a":
         from ldm.modules.diffusionmodules.custom_openaimodel import UNetModel
         kw = dict(use_context_project=False)
@@ -98,7 +98,8 @@ def unet_case(name, cfg, H, W, ctx_len, manifest, n=2, seed=0):
     out = dict(x=x.numpy(), t=t.numpy(), y=y.numpy())
     if ctx is not None:
         out["context"] = ctx.numpy()
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    if save:
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "out std", float(y.std()), "absmax", float(y.abs().max()))
     return m
 
@@ -137,6 +138,54 @@ def ddim_case(name, unet, cfg, manifest, S=10, scale=1.5, seed=0):
                         x_inter=np.stack([t.numpy() for t in inter["x_inter"]]), S=S, scale=scale)
     print(name, "z std", float(z.std()))
     return z
+
+
+def ddim_variant_case(name, unet, ldm, S, scale, ctx_len=None):
+    """The reference DDIMSampler on the other two tools' call patterns:
+    inpaint -- conditioning_key 'concat' (ddpm.py:1404-1406: unet(cat([x] + [c], 1), t)), no guidance (audio-chatgpt.py:513-518);
+    I2A     -- crossattn with a 1-token context and unconditional_guidance_scale 3 (audio-chatgpt.py:245-252)."""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+    concat = ldm["conditioning_key"] == "concat"
+
+    class Shim:
+        def __init__(self):
+            betas = make_beta_schedule("linear", ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+            ac = np.cumprod(1.0 - betas, axis=0)
+            self.num_timesteps = ldm["timesteps"]
+            self.betas = torch.tensor(betas, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+            self.device = torch.device("cpu")
+
+        def apply_model(self, x, t, c):
+            if concat:
+                return unet(torch.cat([x] + [c], dim=1), t)
+            return unet(x, t, context=c)
+
+    sampler = DDIMSampler(Shim())
+    sampler.device = torch.device("cpu")
+    Cz, H, W = ldm["latent_shape"]
+    x_T = torch.from_numpy(np.random.RandomState(55).randn(1, Cz, H, W)).float()
+    out = dict(x_T=x_T.numpy(), S=S, scale=scale)
+    if concat:
+        g = torch.Generator().manual_seed(77)
+        masked = torch.randn(1, Cz, H, W, generator=g)                     # encoded masked mel
+        mask = torch.zeros(1, 1, H, W)
+        mask[:, :, :, W // 3: W // 2] = 1.0                                # the region to fill (make_batch_sd)
+        c = torch.cat([masked * (1 - mask), mask], dim=1)                  # audio-chatgpt.py:507-511
+        out["c"] = c.numpy()
+        kw = dict(conditioning=c)
+    else:
+        c, uc = _cond(1, ctx_len, 1234), _cond(1, ctx_len, 1235)           # image embedding / embedding of "" (audio-chatgpt.py:238-243)
+        out["c"], out["uc"] = c.numpy(), uc.numpy()
+        kw = dict(conditioning=c, unconditional_guidance_scale=scale, unconditional_conditioning=uc)
+    with torch.no_grad():
+        z, _ = sampler.sample(S=S, batch_size=1, shape=[Cz, H, W], verbose=False, x_T=x_T, **kw)
+    out["z"] = z.numpy()
+    out["ddim_timesteps"] = np.asarray(sampler.ddim_timesteps)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "z std", float(z.std()), "absmax", float(z.abs().max()))
 
 
 def vae_case(name, dd, manifest, z=None, seed=1):
@@ -261,8 +310,10 @@ def main():
     manifest = {}
     unet = unet_case("unet_t2a", C.UNET_T2A, 10, 78, 77, manifest)
     z = ddim_case("ddim_t2a_s10", unet, C.UNET_T2A, manifest)
-    unet_case("unet_i2a", C.UNET_I2A, 10, 78, 1, manifest, seed=4)
-    unet_case("unet_inpaint", C.UNET_INPAINT, 10, 106, 0, manifest, n=1, seed=5)
+    u_i2a = unet_case("unet_i2a", C.UNET_I2A, 10, 78, 1, manifest, seed=4)
+    u_inp = unet_case("unet_inpaint", C.UNET_INPAINT, 10, 106, 0, manifest, n=1, seed=5)
+    ddim_variant_case("ddim_i2a_s4", u_i2a, C.LDM_I2A, 4, 3.0, ctx_len=1)
+    ddim_variant_case("ddim_inpaint_s4", u_inp, C.LDM_INPAINT, 4, 1.0)
     mel = vae_case("vae", C.VAE_DDCONFIG, manifest, z=z)
     # plumbing config 1 end to end: clamp((x+1)/2, 0, 1) -> vocoder (audio-chatgpt.py:176-181)
     spec = torch.clamp((mel + 1.0) / 2.0, 0.0, 1.0)[:, 0]
@@ -288,5 +339,17 @@ def main_nsf_only():
     print("torch", torch.__version__)
 
 
+def main_ddim_variants_only():
+    """`python tests/golden/make_golden.py ddimvar`: add the I2A / inpaint sampler cases only."""
+    torch.set_num_threads(8)
+    _install_shims()
+    scratch = {}
+    u_i2a = unet_case("unet_i2a", C.UNET_I2A, 10, 78, 1, scratch, seed=4, save=False)
+    u_inp = unet_case("unet_inpaint", C.UNET_INPAINT, 10, 106, 0, scratch, n=1, seed=5, save=False)
+    ddim_variant_case("ddim_i2a_s4", u_i2a, C.LDM_I2A, 4, 3.0, ctx_len=1)
+    ddim_variant_case("ddim_inpaint_s4", u_inp, C.LDM_INPAINT, 4, 1.0)
+    print("torch", torch.__version__)
+
+
 if __name__ == "__main__":
-    main_nsf_only() if sys.argv[1:] == ["nsf"] else main()
+    {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only}.get(" ".join(sys.argv[1:]), main)()

@@ -168,3 +168,28 @@ def test_vocoder_batch_invariance_and_ragged_lengths(ctx):
         one = v(mel[2:3]).cpu()
         assert torch.equal(one, wav[2:3])
     v.close()
+
+
+def _ddim_variant(ctx, golden, name, cfg, ldm, seed, tol, tag=""):
+    """The device DDIM loop on the I2A (1-token context, scale 3) and inpaint (conditioning_key 'concat', no guidance)
+    call patterns against the reference sampler's output (tests/golden/make_golden.py ddim_variant_case)."""
+    from audiogpt_amd.backend import UNet
+    g = golden(name)
+    u = UNet(ctx, cfg, WT.make_unet_state_dict(cfg, seed=seed))
+    steps, a, ap = _ddim_tables(int(g["S"]), ldm)
+    assert steps.tolist() == g["ddim_timesteps"].tolist()
+    if ldm["conditioning_key"] == "concat":
+        kw = dict(concat=torch.from_numpy(g["c"]))
+    else:
+        kw = dict(cond=torch.from_numpy(g["c"]), uncond=torch.from_numpy(g["uc"]), scale=float(g["scale"]))
+    z = u.ddim_sample(torch.from_numpy(g["x_T"]), steps, a, ap, **kw)
+    z_eager = u.ddim_sample(torch.from_numpy(g["x_T"]), steps, a, ap, use_graph=False, **kw)
+    u.close()
+    assert torch.equal(z, z_eager), "graph replay differs from eager"
+    check(tag + name + "_vs_reference", z, g["z"], tol)
+
+
+@pytest.mark.parametrize("name,cfg,ldm,seed", [("ddim_i2a_s4", C.UNET_I2A, C.LDM_I2A, 4),
+                                               ("ddim_inpaint_s4", C.UNET_INPAINT, C.LDM_INPAINT, 5)])
+def test_ddim_variants_match_reference(golden, ctx, name, cfg, ldm, seed):
+    _ddim_variant(ctx, golden, name, cfg, ldm, seed, 1e-4)

@@ -281,3 +281,10 @@ def test_bf16x3_ddim_graph_replay_is_bit_identical(golden, ctx3):
     z1 = unet.ddim_sample(torch.from_numpy(gd["x_T"]), steps, a, ap, use_graph=True, **args).cpu()
     unet.close()
     assert torch.equal(z0, z1)
+
+
+@pytest.mark.parametrize("name,cfg,ldm,seed", [("ddim_i2a_s4", C.UNET_I2A, C.LDM_I2A, 4),
+                                               ("ddim_inpaint_s4", C.UNET_INPAINT, C.LDM_INPAINT, 5)])
+def test_bf16x3_ddim_variants_match_reference(golden, ctx3, name, cfg, ldm, seed):
+    from tests.test_gpu_models import _ddim_variant
+    _ddim_variant(ctx3, golden, name, cfg, ldm, seed, 1e-3, tag="bf16x3_")

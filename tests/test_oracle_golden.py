@@ -148,3 +148,32 @@ def test_hifigan_nsf_branch_matches_reference(golden):
     exp0 = torch.tanh(torch.nn.functional.linear(noise * (N.SINE_AMP / 3), sd["m_source.l_linear.weight"],
                                                  sd["m_source.l_linear.bias"])).transpose(1, 2)
     assert torch.allclose(har0, exp0, atol=1e-7)
+
+
+def test_ddim_i2a_scale3_matches_reference(golden):
+    """I2A call pattern (audio-chatgpt.py:245-252): 1-token context (also added to the time embedding,
+    custom_openaimodel.py:352-354), guidance scale 3."""
+    g = golden("ddim_i2a_s4")
+    cfg, ldm = C.UNET_I2A, C.LDM_I2A
+    sd = WT.make_unet_state_dict(cfg, seed=4)
+    ac = O_ddim.alphas_cumprod(ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+    assert O_ddim.ddim_timesteps(4).tolist() == g["ddim_timesteps"].tolist() == [1, 251, 501, 751]
+    with torch.no_grad():
+        z = O_ddim.ddim_sample(lambda x, t, c: O_unet.unet_forward(sd, cfg, x, t, c), ac, 4, torch.from_numpy(g["x_T"]),
+                               torch.from_numpy(g["c"]), torch.from_numpy(g["uc"]), scale=float(g["scale"]))
+    ref = g["z"]
+    assert np.abs(z.numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_ddim_inpaint_concat_matches_reference(golden):
+    """Inpaint call pattern (audio-chatgpt.py:507-518): conditioning_key 'concat' -- the UNet sees cat([x, c], 1) with
+    c = [masked latent (4) | mask (1)] (ddpm.py:1404-1406), no guidance; inpaint beta schedule."""
+    g = golden("ddim_inpaint_s4")
+    cfg, ldm = C.UNET_INPAINT, C.LDM_INPAINT
+    sd = WT.make_unet_state_dict(cfg, seed=5)
+    ac = O_ddim.alphas_cumprod(ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+    with torch.no_grad():
+        z = O_ddim.ddim_sample(lambda x, t, c: O_unet.unet_forward(sd, cfg, torch.cat([x, c], dim=1), t, None), ac, 4,
+                               torch.from_numpy(g["x_T"]), torch.from_numpy(g["c"]))
+    ref = g["z"]
+    assert np.abs(z.numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
