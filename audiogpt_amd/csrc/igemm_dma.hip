@@ -515,11 +515,17 @@ void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
             else launch_one<128, 64, 2, 2, 2>(ctx, p, Nb);
             break;
         }
-        default:
+        default: {
+            static const bool lean = std::getenv("MAA_DMA_LEAN") != nullptr;        // experimental, see igemm_dma_lean_kernel
+            if (lean && !p.geglu && !p.dbg) {
+                launch_igemm_dma_lean(ctx, p, Nb);
+                break;
+            }
             if (ns >= 4) launch_one<64, 64, 2, 2, 4>(ctx, p, Nb);
             else if (ns == 3) launch_one<64, 64, 2, 2, 3>(ctx, p, Nb);
             else launch_one<64, 64, 2, 2, 2>(ctx, p, Nb);
             break;
+        }
     }
 }
 

@@ -143,6 +143,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms);   // false: n
 // bf16x3 with LDS-DMA tile copies, both operands split32 (igemm_dma.hip); called by launch_igemm_bf16
 int igemm_dma_tile(const IGemm& p, int cfg);      // tile the DMA engine runs for the generic choice `cfg`
 void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb);
+void launch_igemm_dma_lean(const Ctx& ctx, const IGemm& p, int Nb);   // experimental 64x64 variant (MAA_DMA_LEAN)
 
 // ------------------------------------------------------------------------------------------ norms etc.
 // GroupNorm(32 groups) over a channels-last tensor given as a virtual concat of two sources; writes
