@@ -112,7 +112,6 @@ __global__ __launch_bounds__(NT) void igemm_dma_lean_kernel(const IGemm p, int n
         }
     };
     int g_tap = 0, g_ci = 0;
-    bool past = false;
     auto issue = [&](char* sbase) {            // sbase: this wave's 4 KB slice of the stage (scalar)
 #pragma unroll
         for (int j = 0; j < IPW; ++j) {
@@ -124,7 +123,6 @@ __global__ __launch_bounds__(NT) void igemm_dma_lean_kernel(const IGemm p, int n
             g_ci = 0;
             ++g_tap;
             if (g_tap >= taps) {
-                past = true;
 #pragma unroll
                 for (int j = 0; j < IPW; ++j) {
                     ptr[j] = zero;
