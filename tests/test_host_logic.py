@@ -121,3 +121,37 @@ def test_unet_layer_plan_matches_survey_counts():
     sd = WT.make_unet_state_dict(C.UNET_T2A, seed=0)
     n_params = sum(int(np.prod(v.shape)) for v in sd.values())
     assert abs(n_params - 160.22e6) < 0.05e6                   # 160.2 M parameters
+
+
+def test_pmc_traffic_json_reproduces_committed_number(tmp_path):
+    """Measurement tooling: profiles/r1_pmc_traffic.json (read by bench.py for roofline.traffic) is exactly what
+    scripts/pmc_traffic_json.py derives from the committed PMC summary (FETCH_SIZE doubled on gfx950, KB -> bytes)."""
+    import json
+    import subprocess
+    import sys
+    committed = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+    out = str(tmp_path / "t.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic_json.py"),
+                        os.path.join(ROOT, "profiles", "r1_bf16x3_pmc_fetch_write.txt"), committed["rocprof_kernel_prefix"],
+                        committed["kernel_family"], committed["precision"], out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    again = json.load(open(out))
+    assert again["launches"] == committed["launches"]
+    assert abs(again["hbm_bytes_per_launch"] - committed["hbm_bytes_per_launch"]) < 1.0
+    expect = (2.0 * committed["fetch_kb_sum"] + committed["write_kb_sum"]) / committed["launches"] * 1024.0
+    assert abs(committed["hbm_bytes_per_launch"] - expect) < 1.0
+
+
+def test_bench_line_contract_of_the_committed_run():
+    """The last bench line of the round carries every field of the driver's contract plus roofline and cpu_baseline."""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r1_bf16x3_bench_final.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+    assert abs(d["value"] - d["config"]["audio_seconds_per_step"] / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
