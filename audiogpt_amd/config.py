@@ -85,6 +85,11 @@ HIFIGAN_NS_128 = dict(HIFIGAN_16K, sampling_rate=22050, upsample_initial_channel
 HIFIGAN_NSF_24K = dict(HIFIGAN_16K, sampling_rate=24000, upsample_rates=(8, 4, 2, 2), upsample_kernel_sizes=(16, 8, 4, 4),
                        use_pitch_embed=True)
 
+# DiffSinger denoiser + PLMS loop of the T2S tool (egs_bases/svs/base.yaml:3-5, midi/e2e/opencpop/ds1000.yaml:22-36;
+# checkpoints/0831_opencpop_ds1000): oracle groundwork for SURVEY 8f/N2 only.
+DIFFSINGER_DS1000 = dict(in_dims=80, hidden_size=256, residual_layers=20, residual_channels=256, dilation_cycle_length=4,
+                         timesteps=1000, K_step=1000, max_beta=0.02, pndm_speedup=10)
+
 # BigVGAN's args.yml (vocoder/logs/bigv16k53w) does not ship with the reference
 # (SURVEY.md section 0.3); these are the generator defaults it is exercised with here.
 BIGVGAN_16K = dict(

@@ -310,6 +310,31 @@ def make_vocoder_state_dict(cfg, seed=2):
     return sd
 
 
+def make_diffnet_state_dict(cfg, seed=7):
+    """DiffNet (NeuralSeq/modules/diff/net.py:84-105) in the reference key layout; the zero-initialised
+    output_projection (:105) is re-randomised like the UNet's zero modules."""
+    g = _Gen(seed)
+    C, H, M = cfg["residual_channels"], cfg["hidden_size"], cfg["in_dims"]
+    sd = {"input_projection.weight": g.normal((C, M, 1), 1.0 / math.sqrt(M)), "input_projection.bias": g.bias(C),
+          "mlp.0.weight": g.normal((4 * C, C), 1.0 / math.sqrt(C)), "mlp.0.bias": g.bias(4 * C),
+          "mlp.2.weight": g.normal((C, 4 * C), 1.0 / math.sqrt(4 * C)), "mlp.2.bias": g.bias(C)}
+    for i in range(cfg["residual_layers"]):
+        p = f"residual_layers.{i}."
+        sd[p + "dilated_conv.weight"] = g.normal((2 * C, C, 3), 1.0 / math.sqrt(3 * C))
+        sd[p + "dilated_conv.bias"] = g.bias(2 * C)
+        sd[p + "diffusion_projection.weight"] = g.normal((C, C), 1.0 / math.sqrt(C))
+        sd[p + "diffusion_projection.bias"] = g.bias(C)
+        sd[p + "conditioner_projection.weight"] = g.normal((2 * C, H, 1), 1.0 / math.sqrt(H))
+        sd[p + "conditioner_projection.bias"] = g.bias(2 * C)
+        sd[p + "output_projection.weight"] = g.normal((2 * C, C, 1), 1.0 / math.sqrt(C))
+        sd[p + "output_projection.bias"] = g.bias(2 * C)
+    sd["skip_projection.weight"] = g.normal((C, C, 1), 1.0 / math.sqrt(C))
+    sd["skip_projection.bias"] = g.bias(C)
+    sd["output_projection.weight"] = g.normal((M, C, 1), 1.0 / math.sqrt(C))
+    sd["output_projection.bias"] = g.bias(M)
+    return sd
+
+
 def fold_weight_norm(sd):
     """weight_g / weight_v -> weight, as torch's remove_weight_norm: w = g * v / ||v||_(dims != 0)
     (NeuralSeq/modules/hifigan/hifigan.py:171-178; for ConvTranspose1d dim 0 is the in-channel axis)."""

@@ -285,6 +285,75 @@ def hifigan_nsf_case(name, cfg, T, manifest, B=2, seed=6):
     return wav
 
 
+def diffsinger_case(name, cfg, T, manifest, B=1, seed=7, K_step=60):
+    """Reference DiffNet (modules/diff/net.py) + GaussianDiffusion.p_sample_plms driven exactly like the sampling loop of
+    shallow_diffusion_tts.py:262-269 (gaussian start, pndm_speedup), on a shortened trajectory (K_step 60, interval 10).
+    Batch 1: the reference's first PLMS step evaluates `max(t - interval, 0)` on the timestep tensor (:192), which only
+    works for a single sample -- the T2S tool synthesises one utterance at a time."""
+    import importlib.util
+    from collections import deque
+    hp = dict(hidden_size=cfg["hidden_size"], residual_layers=cfg["residual_layers"],
+              residual_channels=cfg["residual_channels"], dilation_cycle_length=cfg["dilation_cycle_length"],
+              max_beta=cfg["max_beta"], schedule_type="linear")
+    stubs = {"utils": {}, "utils.hparams": {"hparams": hp}, "modules": {}, "modules.diff": {}, "modules.fastspeech": {},
+             "modules.fastspeech.fs2": {"FastSpeech2": object}, "modules.diffsinger_midi": {},
+             "modules.diffsinger_midi.fs2": {"FastSpeech2MIDI": object}}
+    saved = {k: sys.modules.get(k) for k in stubs}
+    for k, attrs in stubs.items():
+        m = types.ModuleType(k)
+        m.__path__ = []
+        for a, v in attrs.items():
+            setattr(m, a, v)
+        sys.modules[k] = m
+
+    def load(modname, rel):
+        sp = importlib.util.spec_from_file_location(modname, os.path.join(NS, rel))
+        m = importlib.util.module_from_spec(sp)
+        sys.modules[modname] = m
+        sp.loader.exec_module(m)
+        return m
+    try:
+        load("modules.diff.diffusion", "modules/diff/diffusion.py")
+        net = load("modules.diff.net", "modules/diff/net.py")
+        sdt = load("modules.diff.shallow_diffusion_tts", "modules/diff/shallow_diffusion_tts.py")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    model = net.DiffNet(cfg["in_dims"]).eval()
+    manifest[name] = _manifest(model)
+    sd = WT.make_diffnet_state_dict(cfg, seed=seed)
+    model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(21)
+    cond = torch.randn(B, cfg["hidden_size"], T, generator=g)
+    x_T = torch.randn(B, 1, cfg["in_dims"], T, generator=g)                 # gaussian_start (:257-260)
+    t0 = torch.tensor([K_step - 10] * B, dtype=torch.long)
+    with torch.no_grad():
+        eps0 = model(x_T, t0, cond)
+
+    betas = sdt.linear_beta_schedule(cfg["timesteps"], max_beta=cfg["max_beta"])
+    ac = torch.tensor(np.cumprod(1.0 - betas, axis=0), dtype=torch.float32)
+
+    class Shim:
+        alphas_cumprod = ac
+        noise_list = deque(maxlen=4)
+
+        @staticmethod
+        def denoise_fn(x, t, cond):
+            return model(x, t, cond)
+    x = x_T
+    inter = []
+    with torch.no_grad():
+        for i in reversed(range(0, K_step, cfg["pndm_speedup"])):
+            x = sdt.GaussianDiffusion.p_sample_plms(Shim, x, torch.full((B,), i, dtype=torch.long), cfg["pndm_speedup"], cond)
+            inter.append(x.numpy().copy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), cond=cond.numpy(), x_T=x_T.numpy(), t0=t0.numpy(), eps0=eps0.numpy(),
+                        x0=x.numpy(), x_inter=np.stack(inter), K_step=K_step, alphas_cumprod=ac.numpy())
+    print(name, "eps std", float(eps0.std()), "x0 std", float(x.std()), "absmax", float(x.abs().max()))
+
+
 def bigvgan_case(name, cfg, T, manifest, seed=3):
     from argparse import Namespace
     from vocoder.bigvgan.models import BigVGAN
@@ -322,6 +391,19 @@ def main():
     hifigan_case("hifigan_ns128", C.HIFIGAN_NS_128, 96, manifest, B=2)
     bigvgan_case("bigvgan_16k", C.BIGVGAN_16K, 48, manifest)
     hifigan_nsf_case("hifigan_nsf_24k", C.HIFIGAN_NSF_24K, 40, manifest)
+    diffsinger_case("diffsinger_ds1000", C.DIFFSINGER_DS1000, 48, manifest)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    print("torch", torch.__version__)
+
+
+def main_diffsinger_only():
+    """`python tests/golden/make_golden.py diffsinger`: add the DiffSinger case without regenerating the others."""
+    torch.set_num_threads(8)
+    _install_shims()
+    with open(os.path.join(HERE, "manifest.json")) as f:
+        manifest = json.load(f)
+    diffsinger_case("diffsinger_ds1000", C.DIFFSINGER_DS1000, 48, manifest)
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     print("torch", torch.__version__)
@@ -352,4 +434,4 @@ def main_ddim_variants_only():
 
 
 if __name__ == "__main__":
-    {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only}.get(" ".join(sys.argv[1:]), main)()
+    {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "diffsinger": main_diffsinger_only}.get(" ".join(sys.argv[1:]), main)()

@@ -177,3 +177,25 @@ def test_ddim_inpaint_concat_matches_reference(golden):
                                torch.from_numpy(g["x_T"]), torch.from_numpy(g["c"]))
     ref = g["z"]
     assert np.abs(z.numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_diffsinger_denoiser_and_plms_loop_match_reference(golden):
+    """Groundwork for SURVEY 8f/N2: oracle/diffsinger.py against the reference DiffNet and GaussianDiffusion.p_sample_plms
+    (6 PLMS steps: the 2-evaluation warm-up step, then the 2nd/3rd/4th-order multistep formulas)."""
+    from oracle import diffsinger as D
+    g = golden("diffsinger_ds1000")
+    cfg = C.DIFFSINGER_DS1000
+    sd = WT.make_diffnet_state_dict(cfg, seed=7)
+    cond, x_T = torch.from_numpy(g["cond"]), torch.from_numpy(g["x_T"])
+    ac = D.alphas_cumprod(cfg["timesteps"], cfg["max_beta"])
+    assert np.array_equal(ac.numpy(), g["alphas_cumprod"])
+    with torch.no_grad():
+        eps0 = D.diffnet_forward(sd, cfg, x_T, torch.from_numpy(g["t0"]), cond)
+        _close(eps0.numpy(), g["eps0"], 2e-5, "eps0")
+        trace = []
+        x0 = D.plms_sample(lambda x, t, c: D.diffnet_forward(sd, cfg, x, t, c), ac, x_T, cond, int(g["K_step"]),
+                           cfg["pndm_speedup"], trace=trace)
+    assert len(trace) == g["x_inter"].shape[0] == 6
+    for i, x in enumerate(trace):
+        _close(x.numpy(), g["x_inter"][i], 5e-5, f"plms step {i}")
+    _close(x0.numpy(), g["x0"], 5e-5, "x0")
