@@ -288,6 +288,13 @@ int maa_vocoder_forward(maa_ctx* ctx, maa_vocoder* v, const float* d_mel, int B,
 }
 
 // ------------------------------------------------------------------------------------------ operators
+// MAA_OP_PRESPLIT=1 (tests): hand the activation to the contraction in the split32 form a normalisation would
+// have written, so the op entry points exercise the LDS-DMA engines too.
+static bool op_presplit(const maa::Ctx& c, int channels, bool other_prologue) {
+    const char* e = std::getenv("MAA_OP_PRESPLIT");
+    return e && *e == '1' && c.dtype != 0 && channels % 32 == 0 && !other_prologue;
+}
+
 int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w, const float* h_bias, int N,
                   int geglu, float* d_y) {
     return guarded([&] {
@@ -298,14 +305,18 @@ int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w
         if (h_bias) s.add("b", h_bias, {N});
         maa::WeightStore ws(ctx->c.dtype != 0);
         maa::Ctx& c = ctx->c;
-        if (geglu) {
-            MAA_CHECK(h_bias, "geglu needs a bias");
-            maa::PackedW pw = ws.pack_geglu(s.sd, "w", "b");
-            maa::linear_into(c, d_a, K, M, K, pw, nullptr, 0, d_y, N / 2, 1);
-        } else {
-            maa::PackedW pw = ws.pack_conv(s.sd, "w", h_bias ? "b" : "", 1, 1);
-            maa::linear_into(c, d_a, K, M, K, pw, nullptr, 0, d_y, N);
-        }
+        MAA_CHECK(!geglu || h_bias, "geglu needs a bias");
+        maa::PackedW pw = geglu ? ws.pack_geglu(s.sd, "w", "b") : ws.pack_conv(s.sd, "w", h_bias ? "b" : "", 1, 1);
+        const bool pre = op_presplit(c, K, false);
+        maa::run_sized(c, [&] {
+            const float* a = d_a;
+            if (pre) {
+                float* sp = c.ws.alloc_f((size_t)M * K);
+                maa::launch_split32_pack(c, d_a, M, K, sp);
+                a = sp;
+            }
+            maa::linear_into(c, a, K, M, K, pw, nullptr, 0, d_y, geglu ? N / 2 : N, geglu, 0, pre ? M : 0);
+        });
         MAA_HIP(hipStreamSynchronize(c.stream));
     });
 }
@@ -325,6 +336,12 @@ int maa_op_conv(maa_ctx* ctx, const float* d_x, int B, int Cin, int H, int W, co
         maa::run_sized(c, [&] {
             maa::T4 x = maa::alloc_t(c, B, H, W, Cin);
             maa::launch_nchw_to_nhwc(c, d_x, B, Cin, H * W, x.p);
+            if (op_presplit(c, Cin, leaky_slope != 0.f)) {
+                maa::T4 xs = maa::alloc_t(c, B, H, W, Cin);
+                maa::launch_split32_pack(c, x.p, (long long)B * H * W, Cin, xs.p);
+                xs.split = true;
+                x = xs;
+            }
             maa::T4 y = maa::alloc_t(c, B, Ho, Wo, Cout);
             maa::ConvOpt o;
             o.KH = KH;
@@ -515,7 +532,10 @@ int maa_op_bench_conv(maa_ctx* ctx, int B, int H, int W, int Cin, int Cout, int 
         maa::ConvOpt o;
         o.KH = o.KW = k;
         o.pad = k / 2;
-        for (int i = 0; i < 3; ++i) maa::conv_into(c, x, nullptr, pw, o, y);
+        // (the split-K engine borrows its slabs from the arena: size it with the warm-up launches)
+        maa::run_sized(c, [&] {
+            for (int i = 0; i < 3; ++i) maa::conv_into(c, x, nullptr, pw, o, y);
+        });
         hipEvent_t e0, e1;
         MAA_HIP(hipEventCreate(&e0));
         MAA_HIP(hipEventCreate(&e1));

@@ -410,6 +410,33 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     }
     static const bool no_dma = std::getenv("MAA_NO_DMA") != nullptr;      // tests: same arithmetic, register staging
     const bool dma = terms == 3 && p.a_split && p.b_split && cfg != 3 && !no_dma;
+    const Dma2Plan plan2 = dma ? igemm_dma2_plan(p) : Dma2Plan();
+    if (plan2.cfg >= 0) {
+        // wide tiles + split-K; the slabs are borrowed from the arena for the duration of the two launches (stream order
+        // protects them from later borrowers)
+        const size_t mk = ctx.ws.mark();
+        const size_t nf = igemm_dma2_workspace_floats(p, plan2);
+        float* part = nf ? ctx.ws.alloc_f(nf) : nullptr;
+        if (!ctx.ws.dry) {
+            const double flops2 = 2.0 * p.M * (double)ncols * p.K;
+            const double bytes2 = 4.0 * ((double)p.K * ncols + (double)p.M * p.N);
+            char shape2[64];
+            const char* name2 = igemm_dma2_name(plan2);
+            if (ctx.prof && ctx.prof->detail) {
+                std::snprintf(shape2, sizeof(shape2), "b2 M%d N%d K%d t%d", p.M, ncols, p.K, taps);
+                name2 = shape2;
+            }
+            ProfScope prof2(ctx, name2, flops2, bytes2);
+            const char* dbg2 = std::getenv("MAA_DBG");          // timing ablations; read per launch like MAA_DMA2
+            IGemm q = p;
+            q.dbg = dbg2 ? std::atoi(dbg2) : 0;
+            launch_igemm_dma2(ctx, q, Nb, plan2, part);
+            MAA_HIP(hipGetLastError());
+        }
+        ctx.ws.release(mk);
+        return true;
+    }
+    if (ctx.ws.dry) return true;
     if (dma) cfg = igemm_dma_tile(p, cfg);
     const double flops = 2.0 * p.M * (double)ncols * p.K * p.Z;
     const double bytes = 4.0 * ((double)p.K * ncols + (double)p.M * p.N * p.Z);

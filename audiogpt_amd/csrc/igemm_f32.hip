@@ -358,14 +358,15 @@ inline double tile_cost(long long M, long long N, int Z, int BM, int BN, double 
 }  // namespace
 
 void launch_igemm(const Ctx& ctx, const IGemm& p_in) {
-    if (ctx.ws.dry) return;
     IGemm p = p_in;
     p.zeros = ctx.zeros;
     MAA_CHECK(p.zeros != nullptr, "context has no zero page");
     // precision mode of the context: 1 = bf16x3 split, 2 = plain bf16 operands; problems the bf16 engine cannot
-    // take (B not k-contiguous, odd channel counts) run on the exact-fp32 kernel below
+    // take (B not k-contiguous, odd channel counts) run on the exact-fp32 kernel below.  (launch_igemm_bf16 also runs
+    // in the workspace dry run: its split-K slabs come from the arena.)
     if (ctx.dtype == 1 && launch_igemm_bf16(ctx, p, 3)) return;
     if (ctx.dtype == 2 && launch_igemm_bf16(ctx, p, 1)) return;
+    if (ctx.ws.dry) return;
     MAA_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty igemm");
     MAA_CHECK(!p.c_split, "split32 output asked of a problem only the fp32 engine can take");
     const int taps = p.KH * p.KW, Ctot = p.C1 + p.C2;

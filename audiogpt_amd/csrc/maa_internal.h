@@ -86,7 +86,7 @@ struct Ctx {
     float* zeros = nullptr;   // 256 B zero page (device), source of masked tile loads
     int device = 0;
     hipStream_t stream = nullptr;
-    Arena ws;
+    mutable Arena ws;    // (mutable: a launch may borrow scratch, e.g. split-K slabs, and give it back before it returns)
     int dtype = 0;   // 0 = fp32 (exact-f32 MFMA); 1 = bf16 MFMA operands, fp32 accumulate/storage
 };
 
@@ -144,6 +144,16 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms);   // false: n
 int igemm_dma_tile(const IGemm& p, int cfg);      // tile the DMA engine runs for the generic choice `cfg`
 void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb);
 void launch_igemm_dma_lean(const Ctx& ctx, const IGemm& p, int Nb);   // experimental 64x64 variant (MAA_DMA_LEAN)
+// second LDS-DMA engine (igemm_dma2.hip): 128x128 / 256x128 tiles, 64x64 outputs per wave, split-K finished by a
+// fixed-order reduce kernel.  `takes` and the slab size depend on the layer (K, packed N) only, never on M.
+struct Dma2Plan {
+    int cfg = -1;       // -1: not taken.  0: 128x128 / 4 waves, 1: 256x128 / 8 waves
+    int ns = 2, pipe = 0, S = 1;
+};
+Dma2Plan igemm_dma2_plan(const IGemm& p);
+size_t igemm_dma2_workspace_floats(const IGemm& p, const Dma2Plan& pl);      // 0: no split-K for this problem
+const char* igemm_dma2_name(const Dma2Plan& pl);
+void launch_igemm_dma2(const Ctx& ctx, const IGemm& p, int Nb, const Dma2Plan& pl, float* part);
 
 // ------------------------------------------------------------------------------------------ norms etc.
 // GroupNorm(32 groups) over a channels-last tensor given as a virtual concat of two sources; writes
@@ -155,6 +165,9 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
                       int out_split = 0);
 void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, const float* gamma, const float* beta,
                       float eps, float* out, int out_split = 0);
+// fp32 [rows, C] -> split32 rows of the same pitch (C % 32 == 0): tests and micro-benchmarks of the engines that take
+// pre-split activations (in the models the normalisations write this form directly)
+void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, float* out);
 // fused softmax(alpha q k^T) v for the bf16 precision modes; false = shape not covered, use the GEMM path
 bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
                             const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,

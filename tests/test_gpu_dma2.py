@@ -1,0 +1,141 @@
+"""The wide-tile / split-K LDS-DMA engine (csrc/igemm_dma2.hip) at the operator level.
+
+Every (tile, stages, in-wave pipelining, K slices) instantiation is forced onto every eligible problem (MAA_DMA2) with
+the activation handed over pre-split (MAA_OP_PRESPLIT=1, the form the normalisations write inside the models) and
+compared with torch.nn.functional in fp32 on the CPU at the bf16x3 operator tolerance (rel-max 2e-4).  Plus the
+engine's two contracts: S = 1 is bit-identical to the other bf16x3 engines, and results do not depend on the batch.
+"""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import check
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+# cfg (0: 128x128 / 4 waves, 1: 256x128 / 8 waves), LDS stages, in-wave pipelining, K slices
+VARIANTS = ["0,2,0,1", "0,2,0,4", "0,3,0,3", "0,3,1,2", "0,4,1,5", "1,2,0,2", "1,3,0,1", "1,3,1,3"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from audiogpt_amd.backend import Context
+    c = Context("cuda:0", precision="bf16x3")
+    yield c
+    c.close()
+
+
+class forced:
+    """Environment for one call: MAA_DMA2 is read by the library on every launch."""
+
+    def __init__(self, dma2, presplit=True):
+        self.env = {"MAA_DMA2": dma2, "MAA_OP_PRESPLIT": "1" if presplit else "0"}
+
+    def __enter__(self):
+        self.saved = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
+    def __exit__(self, *a):
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+CONVS = [  # B, Cin, Cout, H, W, stride, up
+    (2, 320, 320, 10, 78, 1, False),      # M = 1560 (ragged against 128 and 256), K = 2880
+    (2, 320, 320, 10, 78, 2, False),      # strided gather
+    (2, 640, 640, 5, 39, 1, True),        # virtual nearest-2x upsample, K = 5760
+    (3, 64, 96, 7, 9, 1, False),          # N < one tile, 18 chunks: fewer chunks than some slice counts ask for
+    (1, 96, 200, 5, 39, 1, False),        # M = 195 < one tile, N not a multiple of 32
+]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride,up", CONVS)
+def test_conv3x3(ctx, variant, B, Cin, Cout, H, W, stride, up):
+    x = torch.randn(B, Cin, H, W, generator=g(7))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(8)) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g(9))
+    with forced(variant):
+        y = ctx.op_conv(x, w, b, stride=stride, pad=1, up=up)
+    xr = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    check(f"dma2[{variant}]_conv3x3_{Cin}_{Cout}_{H}x{W}_s{stride}_up{int(up)}", y,
+          F.conv2d(xr, w, b, stride=stride, padding=1), TOL)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("M,K,N,bias", [(1560, 320, 320, True), (390, 640, 640, False), (130, 2560, 640, True),
+                                         (257, 64, 77, False), (16, 1280, 6080, True)])
+def test_linear(ctx, variant, M, K, N, bias):
+    a = torch.randn(M, K, generator=g(1))
+    w = torch.randn(N, K, generator=g(2)) / math.sqrt(K)
+    b = torch.randn(N, generator=g(3)) if bias else None
+    with forced(variant):
+        y = ctx.op_linear(a, w, b)
+    check(f"dma2[{variant}]_linear_{M}x{K}x{N}", y, F.linear(a, w, b), TOL)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_linear_geglu(ctx, variant):
+    a = torch.randn(1560, 320, generator=g(4))
+    w = torch.randn(2560, 320, generator=g(5)) / math.sqrt(320)
+    b = torch.randn(2560, generator=g(6)) * 0.1
+    val, gate = F.linear(a, w, b).chunk(2, dim=-1)
+    with forced(variant):
+        y = ctx.op_linear(a, w, b, geglu=True)
+    check(f"dma2[{variant}]_geglu", y, val * F.gelu(gate), TOL)
+
+
+def test_identity_asymmetric(ctx):
+    """A = I against an asymmetric B: catches a transposed or mis-placed output block (fragment map, slab layout)."""
+    K = N = 256
+    a = torch.eye(K)
+    w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 17.0 + torch.arange(N)[:, None] * 0.5
+    for variant in ("0,2,0,1", "0,2,0,4", "1,3,1,2"):
+        with forced(variant):
+            y = ctx.op_linear(a, w)
+        check(f"dma2[{variant}]_identity", y, w.t().contiguous(), TOL)
+
+
+@pytest.mark.parametrize("variant", ["0,2,0,1", "0,3,0,1", "0,3,1,1", "0,4,1,1", "1,2,0,1", "1,3,1,1"])
+def test_one_slice_is_bit_identical_to_the_other_engines(ctx, variant):
+    """Same products in the same order per accumulator: without a K split this engine, the 64x64 LDS-DMA engine and the
+    register-staged engine agree bit for bit."""
+    x = torch.randn(2, 320, 10, 78, generator=g(11))
+    w = torch.randn(320, 320, 3, 3, generator=g(12)) / math.sqrt(2880)
+    b = torch.randn(320, generator=g(13))
+    with forced("off"):
+        y_dma = ctx.op_conv(x, w, b, pad=1).cpu()
+    with forced("off", presplit=False):
+        y_reg = ctx.op_conv(x, w, b, pad=1).cpu()
+    with forced(variant):
+        y = ctx.op_conv(x, w, b, pad=1).cpu()
+    assert torch.equal(y, y_dma)
+    assert torch.equal(y, y_reg)
+
+
+@pytest.mark.parametrize("variant", ["0,2,0,4", "1,3,1,3", None])
+def test_split_k_is_deterministic_and_batch_invariant(ctx, variant):
+    """Slices are added in slice order by a separate kernel and their number depends on the layer only: repeated runs
+    are bit-identical, and a sample's rows do not change with the batch they are computed in (None = default policy)."""
+    x = torch.randn(6, 640, 5, 39, generator=g(21))
+    w = torch.randn(640, 640, 3, 3, generator=g(22)) / math.sqrt(5760)
+    b = torch.randn(640, generator=g(23))
+    env = forced(variant) if variant else forced("", presplit=True)
+    with env:
+        y6 = ctx.op_conv(x, w, b, pad=1).cpu()
+        y6b = ctx.op_conv(x, w, b, pad=1).cpu()
+        y1 = ctx.op_conv(x[4:5], w, b, pad=1).cpu()
+    assert torch.equal(y6, y6b)
+    assert torch.equal(y6[4:5], y1)
+    check(f"dma2[{variant}]_conv_640_b6", y6, F.conv2d(x, w, b, padding=1), TOL)
