@@ -12,6 +12,16 @@ import torch
 from . import _lib as L
 
 
+def default_precision():
+    """Precision mode of the drop-in tool / sampler / vocoder classes when none is given: bf16x3 (meets the fp32
+    parity gates), overridable with AUDIOGPT_AMD_PRECISION=f32|bf16x3|bf16."""
+    import os
+    p = os.environ.get("AUDIOGPT_AMD_PRECISION", "bf16x3")
+    if p not in Context.PRECISIONS:
+        raise ValueError("AUDIOGPT_AMD_PRECISION must be one of %s" % sorted(Context.PRECISIONS))
+    return p
+
+
 def _f32(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
@@ -226,17 +236,31 @@ class UNet:
         a.S, a.B, a.C, a.H, a.W = len(ts), B, Cc, H, W
         a.scale = float(scale)
         keep = []
+        # shapes are checked here (the C ABI sees bare pointers): the reference raises from torch.cat / the attention
+        # einsum on any of these mismatches (ddim.py:177-199, ddpm.py:1404-1406)
         if cond is not None:
             cond = _f32(cond, dev)
+            cdim = self.cfg["context_dim"] or 0
+            if cond.dim() != 3 or cond.shape[0] != B or cond.shape[2] != cdim:
+                raise L.MaaError("ddim_sample: conditioning must be [B=%d, L, %d], got %s" % (B, cdim, tuple(cond.shape)))
             keep.append(cond)
             a.d_cond = cond.data_ptr()
             a.L = cond.shape[1]
         if uncond is not None:
+            if cond is None:
+                raise L.MaaError("ddim_sample: unconditional_conditioning without conditioning")
             uncond = _f32(uncond, dev)
+            if tuple(uncond.shape) != tuple(cond.shape):
+                raise L.MaaError("ddim_sample: unconditional_conditioning %s must have the shape of conditioning %s"
+                                 % (tuple(uncond.shape), tuple(cond.shape)))
             keep.append(uncond)
             a.d_uncond = uncond.data_ptr()
         if concat is not None:
             concat = _f32(concat, dev)
+            if concat.dim() != 4 or concat.shape[0] != B or tuple(concat.shape[2:]) != (H, W) \
+                    or Cc + concat.shape[1] != self.cfg["in_channels"]:
+                raise L.MaaError("ddim_sample: concat conditioning must be [B=%d, %d, %d, %d], got %s"
+                                 % (B, self.cfg["in_channels"] - Cc, H, W, tuple(concat.shape)))
             keep.append(concat)
             a.d_concat = concat.data_ptr()
             a.Cc = concat.shape[1]

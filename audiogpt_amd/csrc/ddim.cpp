@@ -13,21 +13,11 @@
 
 namespace maa {
 
-namespace {
-struct DevBuf {
-    void* p = nullptr;
-    explicit DevBuf(size_t bytes) { MAA_HIP(hipMalloc(&p, bytes ? bytes : 4)); }
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    float* f() const { return static_cast<float*>(p); }
-};
-}  // namespace
-
 void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
     MAA_CHECK(a.S > 0 && a.B > 0, "ddim: empty problem");
+    MAA_CHECK(!a.d_uncond || a.d_cond, "ddim: unconditional conditioning given without conditioning");
+    MAA_CHECK(!a.d_cond || a.L > 0, "ddim: conditioning needs its token count L");
+    MAA_CHECK(!a.d_concat || a.Cc > 0, "ddim: concat conditioning needs its channel count");
     const bool concat = a.d_concat != nullptr;
     const bool cfg = !concat && a.d_uncond != nullptr && a.scale != 1.0f;
     const int nB = cfg ? 2 * a.B : a.B;
@@ -36,59 +26,49 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
     const long long per_in = (long long)Cin * a.H * a.W;
     MAA_CHECK(unet.config().in_channels == Cin, "ddim: UNet in_channels does not match latent (+concat) channels");
 
-    // ---- device tables: one row per DDIM index
-    std::vector<float> h_t((size_t)a.S * nB), h_coef((size_t)a.S * 4);
+    // ---- device state of the loop, in one slab the context keeps across calls: tables (one row per DDIM index), the
+    // device step index, the step's timestep / coefficient slots, UNet input and output
+    std::vector<float> h_tab((size_t)a.S * 5);
     for (int i = 0; i < a.S; ++i) {
-        for (int b = 0; b < nB; ++b) h_t[(size_t)i * nB + b] = (float)a.h_timesteps[i];
-        h_coef[(size_t)i * 4 + 0] = a.h_alphas[i];
-        h_coef[(size_t)i * 4 + 1] = a.h_alphas_prev[i];
-        h_coef[(size_t)i * 4 + 2] = 0.f;                                   // eta = 0
-        h_coef[(size_t)i * 4 + 3] = std::sqrt(1.0f - a.h_alphas[i]);       // ddim.py:52 (fp32 sqrt of fp32 1-a)
+        h_tab[i] = (float)a.h_timesteps[i];
+        float* cf = &h_tab[(size_t)a.S + (size_t)i * 4];
+        cf[0] = a.h_alphas[i];
+        cf[1] = a.h_alphas_prev[i];
+        cf[2] = 0.f;                                   // eta = 0
+        cf[3] = std::sqrt(1.0f - a.h_alphas[i]);       // ddim.py:52 (fp32 sqrt of fp32 1-a)
     }
-    DevBuf tab_t(h_t.size() * 4), tab_coef(h_coef.size() * 4), cur_t((size_t)nB * 4), cur_coef(16);
-    DevBuf xin((size_t)nB * per_in * 4), eps((size_t)nB * per * 4), ctxbuf(cfg ? (size_t)nB * a.L * unet.config().context_dim * 4 : 4);
-    MAA_HIP(hipMemcpyAsync(tab_t.p, h_t.data(), h_t.size() * 4, hipMemcpyHostToDevice, ctx.stream));
-    MAA_HIP(hipMemcpyAsync(tab_coef.p, h_coef.data(), h_coef.size() * 4, hipMemcpyHostToDevice, ctx.stream));
+    auto up = [](size_t n) { return (n + 63) / 64 * 64; };      // floats, 256-byte aligned pieces
+    const size_t o_tab = 0, o_step = o_tab + up(h_tab.size()), o_t = o_step + 64, o_coef = o_t + up(nB),
+                 o_xin = o_coef + 64, o_eps = o_xin + up((size_t)nB * per_in), total = o_eps + up((size_t)nB * per);
+    float* slab = static_cast<float*>(ctx.sampler_scratch.get(total * sizeof(float), ctx.stream));
+    float *tab_t = slab + o_tab, *tab_coef = slab + o_tab + a.S, *cur_t = slab + o_t, *cur_coef = slab + o_coef,
+          *xin = slab + o_xin, *eps = slab + o_eps;
+    int* d_step = reinterpret_cast<int*>(slab + o_step);
+    const int h_step = a.S - 1;                        // ddim.py:143-145: flipped timesteps, index = total - i - 1
+    MAA_HIP(hipMemcpyAsync(slab + o_tab, h_tab.data(), h_tab.size() * 4, hipMemcpyHostToDevice, ctx.stream));
+    MAA_HIP(hipMemcpyAsync(d_step, &h_step, 4, hipMemcpyHostToDevice, ctx.stream));
 
     // ---- conditioning: constant over the trajectory -> project K/V once
     if (!concat && a.d_cond) {
-        const size_t cbytes = (size_t)a.B * a.L * unet.config().context_dim * 4;
-        if (cfg) {
-            MAA_HIP(hipMemcpyAsync(ctxbuf.p, a.d_uncond, cbytes, hipMemcpyDeviceToDevice, ctx.stream));
-            MAA_HIP(hipMemcpyAsync(static_cast<char*>(ctxbuf.p) + cbytes, a.d_cond, cbytes, hipMemcpyDeviceToDevice,
-                                   ctx.stream));
-            unet.set_context(ctx, ctxbuf.f(), nB, a.L);
-        } else {
+        if (cfg)
+            unet.set_context_cfg(ctx, a.d_uncond, a.d_cond, a.B, a.L);
+        else
             unet.set_context(ctx, a.d_cond, nB, a.L);
-        }
     }
 
+    // one step: identical launches on identical addresses whatever the step (the index lives on the device)
     auto step_body = [&]() {
-        // UNet input
-        if (cfg) {
-            MAA_HIP(hipMemcpyAsync(xin.p, d_x, (size_t)a.B * per * 4, hipMemcpyDeviceToDevice, ctx.stream));
-            MAA_HIP(hipMemcpyAsync(xin.f() + a.B * per, d_x, (size_t)a.B * per * 4, hipMemcpyDeviceToDevice, ctx.stream));
-        } else if (concat) {
-            MAA_HIP(hipMemcpy2DAsync(xin.p, (size_t)per_in * 4, d_x, (size_t)per * 4, (size_t)per * 4, a.B,
-                                     hipMemcpyDeviceToDevice, ctx.stream));
-            MAA_HIP(hipMemcpy2DAsync(xin.f() + per, (size_t)per_in * 4, a.d_concat, (size_t)(per_in - per) * 4,
-                                     (size_t)(per_in - per) * 4, a.B, hipMemcpyDeviceToDevice, ctx.stream));
-        } else {
-            MAA_HIP(hipMemcpyAsync(xin.p, d_x, (size_t)a.B * per * 4, hipMemcpyDeviceToDevice, ctx.stream));
-        }
-        unet.forward(ctx, xin.f(), cur_t.f(), unet.context_ptr, nB, a.H, a.W, eps.f());
-        launch_ddim_update(ctx, d_x, eps.f(), cfg ? eps.f() + a.B * per : nullptr, a.scale, cur_coef.f(),
-                           (long long)a.B * per, d_x, nullptr);
+        launch_ddim_prepare(ctx, d_x, concat ? a.d_concat : nullptr, a.B, nB, per, per_in - per, tab_t, tab_coef, d_step,
+                            xin, cur_t, cur_coef);
+        unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps);
+        launch_ddim_update(ctx, d_x, eps, cfg ? eps + a.B * per : nullptr, a.scale, cur_coef, (long long)a.B * per, d_x,
+                           nullptr, d_step);
     };
 
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     try {
         for (int i = 0; i < a.S; ++i) {
-            const int index = a.S - 1 - i;       // ddim.py:143-145: flipped timesteps, index = total - i - 1
-            MAA_HIP(hipMemcpyAsync(cur_t.p, tab_t.f() + (size_t)index * nB, (size_t)nB * 4, hipMemcpyDeviceToDevice,
-                                   ctx.stream));
-            MAA_HIP(hipMemcpyAsync(cur_coef.p, tab_coef.f() + (size_t)index * 4, 16, hipMemcpyDeviceToDevice, ctx.stream));
             if (!a.use_graph || i == 0) {
                 step_body();                      // first step eager: sizes the workspace before any capture
             } else {
@@ -108,7 +88,7 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
                 MAA_HIP(hipGraphLaunch(exec, ctx.stream));
             }
         }
-        MAA_HIP(hipStreamSynchronize(ctx.stream));   // host tables and scratch buffers go out of scope
+        MAA_HIP(hipStreamSynchronize(ctx.stream));   // the host tables go out of scope; the call returns a finished latent
     } catch (...) {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);

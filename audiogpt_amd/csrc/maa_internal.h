@@ -81,7 +81,19 @@ struct ProfScope {     // records an event pair around the launches issued durin
     size_t idx_ = 0;
 };
 
+// grow-only device buffer owned by a context / model (growing synchronises the stream first: never inside a capture)
+struct DevSlab {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~DevSlab();
+    void* get(size_t bytes, hipStream_t stream);
+    DevSlab() = default;
+    DevSlab(const DevSlab&) = delete;
+    DevSlab& operator=(const DevSlab&) = delete;
+};
+
 struct Ctx {
+    DevSlab sampler_scratch;  // DDIM loop state (tables, step slots, UNet input, eps): reused by every sample() call
     Profiler* prof = nullptr;
     float* zeros = nullptr;   // 256 B zero page (device), source of masked tile loads
     int device = 0;
@@ -187,8 +199,14 @@ void launch_upsample2(const Ctx& ctx, const float* x, int B, int H, int W, int C
 void launch_scale(const Ctx& ctx, const float* x, long long n, float s, float* out);
 // eps = eu + scale*(ec - eu); x0 = (x - somat*eps)/sqrt(a_t); x' = sqrt(a_prev)*x0 + sqrt(1-a_prev-sig^2)*eps
 // coef = device pointer to {a_t, a_prev, sigma, sqrt_one_minus_at}; eps_c may be null (no CFG)
+// step (optional): device DDIM index, decremented for the next step
 void launch_ddim_update(const Ctx& ctx, const float* x, const float* eps_u, const float* eps_c, float scale,
-                        const float* coef, long long n, float* x_prev, float* pred_x0);
+                        const float* coef, long long n, float* x_prev, float* pred_x0, int* step = nullptr);
+// UNet input of a step (latents duplicated for CFG when nB = 2B, or concatenated with the inpaint conditioning) and the
+// step's timestep / coefficient slots, selected from device tables by the device index *step
+void launch_ddim_prepare(const Ctx& ctx, const float* x, const float* concat, int B, int nB, long long per,
+                         long long per_c, const float* tab_t, const float* tab_coef, const int* step, float* xin,
+                         float* cur_t, float* cur_coef);
 // BigVGAN Activation1d on [B, L, C]: up2 FIR -> snake -> down2 FIR (replicate padding)
 void launch_snake_aa(const Ctx& ctx, const float* x, int B, int L, int C, const float* inv_beta, const float* alpha,
                      float* out);

@@ -116,9 +116,11 @@ __global__ void upsample2_kernel(const float* __restrict__ x, int B, int H, int 
     }
 }
 
-__global__ void ddim_update_kernel(const float* __restrict__ x, const float* __restrict__ eu,
-                                   const float* __restrict__ ec, float scale, const float* __restrict__ coef,
-                                   long long n, float* __restrict__ x_prev, float* __restrict__ pred_x0) {
+// (x and x_prev may be the same buffer -- the sampler updates the latent in place -- so neither is __restrict__)
+__global__ void ddim_update_kernel(const float* x, const float* __restrict__ eu, const float* __restrict__ ec, float scale,
+                                   const float* __restrict__ coef, long long n, float* x_prev,
+                                   float* __restrict__ pred_x0, int* __restrict__ step) {
+    if (step && blockIdx.x == 0 && threadIdx.x == 0) *step = *step - 1;      // next DDIM index (read by the next prepare)
     const float a_t = coef[0], a_prev = coef[1], sigma = coef[2], somat = coef[3];
     const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev), dir = sqrtf(1.f - a_prev - sigma * sigma);
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -127,6 +129,27 @@ __global__ void ddim_update_kernel(const float* __restrict__ x, const float* __r
         const float x0 = (x[i] - somat * e) / sqrt_at;
         x_prev[i] = sqrt_ap * x0 + dir * e;
         if (pred_x0) pred_x0[i] = x0;
+    }
+}
+
+// UNet input and scalars of one DDIM step, with nothing from the host: idx = *step selects the row of the device
+// tables; xin[b'] = cat(x[b' % B], concat[b' % B]) for b' < nB (nB = 2B duplicates the latents for CFG in the order
+// [uncond ; cond], ddim.py:177-179; concat is the inpaint model's conditioning, ddpm.py:1404-1406).
+__global__ void ddim_prepare_kernel(const float* __restrict__ x, const float* __restrict__ concat, int B, int nB,
+                                    long long per, long long per_c, const float* __restrict__ tab_t,
+                                    const float* __restrict__ tab_coef, const int* __restrict__ step,
+                                    float* __restrict__ xin, float* __restrict__ cur_t, float* __restrict__ cur_coef) {
+    const int idx = *step;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < nB) cur_t[threadIdx.x] = tab_t[idx];
+        if (threadIdx.x < 4) cur_coef[threadIdx.x] = tab_coef[idx * 4 + threadIdx.x];
+    }
+    const long long per_in = per + per_c, n = (long long)nB * per_in;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int bb = (int)(i / per_in);
+        const long long r = i - bb * per_in;
+        const int b = bb % B;
+        xin[i] = r < per ? x[b * per + r] : concat[b * per_c + (r - per)];
     }
 }
 
@@ -242,8 +265,15 @@ void launch_upsample2(const Ctx& ctx, const float* x, int B, int H, int W, int C
     MAA_LAUNCH1(upsample2_kernel, (long long)B * H * W * C * 4, x, B, H, W, C, out);
 }
 void launch_ddim_update(const Ctx& ctx, const float* x, const float* eps_u, const float* eps_c, float scale,
-                        const float* coef, long long n, float* x_prev, float* pred_x0) {
-    MAA_LAUNCH1(ddim_update_kernel, n, x, eps_u, eps_c, scale, coef, n, x_prev, pred_x0);
+                        const float* coef, long long n, float* x_prev, float* pred_x0, int* step) {
+    MAA_LAUNCH1(ddim_update_kernel, n, x, eps_u, eps_c, scale, coef, n, x_prev, pred_x0, step);
+}
+void launch_ddim_prepare(const Ctx& ctx, const float* x, const float* concat, int B, int nB, long long per,
+                         long long per_c, const float* tab_t, const float* tab_coef, const int* step, float* xin,
+                         float* cur_t, float* cur_coef) {
+    MAA_CHECK(nB <= 256, "ddim: at most 256 UNet rows per step");
+    MAA_LAUNCH1(ddim_prepare_kernel, (long long)nB * (per + per_c), x, concat, B, nB, per, per_c, tab_t, tab_coef, step,
+                xin, cur_t, cur_coef);
 }
 
 static bool g_fir_uploaded[16] = {false};

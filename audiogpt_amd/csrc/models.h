@@ -12,6 +12,9 @@ public:
     UNet(const maa_unet_config& cfg, const StateDict& sd, int precision);
     ~UNet();
     void set_context(Ctx& ctx, const float* d_context, int B, int L);
+    // classifier-free guidance: context rows [uncond (B) ; cond (B)] assembled in a buffer the UNet owns (it stays
+    // valid for later forwards, e.g. the I2A time-embedding add), then set_context over 2B rows
+    void set_context_cfg(Ctx& ctx, const float* d_uncond, const float* d_cond, int B, int L);
     void forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
                  float* out_nchw);
     const maa_unet_config& config() const;

@@ -38,6 +38,24 @@ float* Arena::alloc_f(size_t n_floats) {
     return reinterpret_cast<float*>(base_ + at);
 }
 
+DevSlab::~DevSlab() {
+    if (p) (void)hipFree(p);
+}
+void* DevSlab::get(size_t bytes, hipStream_t stream) {
+    if (bytes > cap) {
+        if (p) {
+            MAA_HIP(hipStreamSynchronize(stream));      // earlier launches may still read the old buffer
+            MAA_HIP(hipFree(p));
+            p = nullptr;
+            cap = 0;
+        }
+        const size_t want = bytes + bytes / 4;
+        MAA_HIP(hipMalloc(&p, want));
+        cap = want;
+    }
+    return p;
+}
+
 // ------------------------------------------------------------------------------------------ Profiler
 Profiler::~Profiler() {
     for (hipEvent_t e : pool) (void)hipEventDestroy(e);

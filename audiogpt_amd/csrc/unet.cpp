@@ -74,10 +74,11 @@ struct UNet::Impl {
     std::vector<int> kv_inner;
     int kv_rows = 0, kv_len = 0, kv_batch = 0;
     size_t kv_cap_rows = 0;
-    std::vector<void*> owned;
+    DevSlab cfg_context;      // [uncond ; cond] rows of a CFG sample() call
 
     ~Impl() {
-        for (void* p : owned) (void)hipFree(p);
+        for (float* p : kv_cache)
+            if (p) (void)hipFree(p);
     }
 
     // ---- construction ---------------------------------------------------------------------------
@@ -481,10 +482,12 @@ void UNet::set_context(Ctx& ctx, const float* context, int B, int L) {
     PrecisionGuard pg(ctx, m.precision);
     const size_t rows = (size_t)B * L;
     if (rows > m.kv_cap_rows) {
+        MAA_HIP(hipStreamSynchronize(ctx.stream));      // the old caches may still be read by queued launches
         for (size_t i = 0; i < m.kv_cache.size(); ++i) {
+            if (m.kv_cache[i]) MAA_HIP(hipFree(m.kv_cache[i]));
+            m.kv_cache[i] = nullptr;
             void* d = nullptr;
             MAA_HIP(hipMalloc(&d, rows * 2 * m.kv_inner[i] * sizeof(float)));
-            m.owned.push_back(d);
             m.kv_cache[i] = static_cast<float*>(d);
         }
         m.kv_cap_rows = rows;
@@ -496,6 +499,15 @@ void UNet::set_context(Ctx& ctx, const float* context, int B, int L) {
     m.kv_batch = B;
     m.kv_len = L;
     context_ptr = context;
+}
+
+void UNet::set_context_cfg(Ctx& ctx, const float* d_uncond, const float* d_cond, int B, int L) {
+    Impl& m = *impl_;
+    const size_t half = (size_t)B * L * m.cfg.context_dim * sizeof(float);
+    char* buf = static_cast<char*>(m.cfg_context.get(2 * half, ctx.stream));
+    MAA_HIP(hipMemcpyAsync(buf, d_uncond, half, hipMemcpyDeviceToDevice, ctx.stream));
+    MAA_HIP(hipMemcpyAsync(buf + half, d_cond, half, hipMemcpyDeviceToDevice, ctx.stream));
+    set_context(ctx, reinterpret_cast<const float*>(buf), 2 * B, L);
 }
 
 void UNet::forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,

@@ -17,7 +17,7 @@ import torch
 
 from .. import config as C
 from .. import weights as WT
-from ..backend import Context, UNet, VAE
+from ..backend import Context, UNet, VAE, default_precision
 from ..pipeline import alphas_cumprod_f32, make_beta_schedule_linear
 
 
@@ -88,13 +88,15 @@ class _FirstStage(object):
 
 
 class LatentDiffusionAudio(object):
-    def __init__(self, ldm_config=None, device="cuda:0", state_dict=None, seeds=(0, 1), cond_stage_model=None):
+    def __init__(self, ldm_config=None, device="cuda:0", state_dict=None, seeds=(0, 1), cond_stage_model=None,
+                 precision=None):
         self.cfg = ldm_config or C.LDM_T2A
         self.conditioning_key = self.cfg["conditioning_key"]
         self.num_timesteps = self.cfg["timesteps"]
         betas = make_beta_schedule_linear(self.num_timesteps, self.cfg["linear_start"], self.cfg["linear_end"])
         ac = alphas_cumprod_f32(self.num_timesteps, self.cfg["linear_start"], self.cfg["linear_end"])
-        self.ctx = Context(device)
+        self.precision = precision or default_precision()
+        self.ctx = Context(device, precision=self.precision)
         self.device = self.ctx.device
         self.betas = torch.tensor(betas, dtype=torch.float32, device=self.device)
         self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32, device=self.device)

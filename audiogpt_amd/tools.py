@@ -38,15 +38,17 @@ def _write_wav(path, wav, sr):
 
 
 class T2A:
-    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, cond_stage_model=None, scorer=None):
+    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, cond_stage_model=None, scorer=None,
+                 precision=None):
         print("Initializing Make-An-Audio to %s" % device)
         self.device = device
-        self.sampler = self._initialize_model(C.LDM_T2A, ckpt_state_dict, device, cond_stage_model)
+        self.sampler = self._initialize_model(C.LDM_T2A, ckpt_state_dict, device, cond_stage_model, precision)
         self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=self.sampler.model.ctx)
         self.scorer = scorer
 
-    def _initialize_model(self, config, ckpt, device, cond_stage_model=None):
-        model = LatentDiffusionAudio(config, device=device, state_dict=ckpt, cond_stage_model=cond_stage_model)
+    def _initialize_model(self, config, ckpt, device, cond_stage_model=None, precision=None):
+        model = LatentDiffusionAudio(config, device=device, state_dict=ckpt, cond_stage_model=cond_stage_model,
+                                     precision=precision)
         return DDIMSampler(model)
 
     def txt2audio(self, text, seed=55, scale=1.5, ddim_steps=100, n_samples=3, W=624, H=80):
@@ -84,11 +86,11 @@ class T2A:
 
 
 class I2A:
-    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, cond_stage_model=None):
+    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, cond_stage_model=None, precision=None):
         print("Initializing Make-An-Audio-Image to %s" % device)
         self.device = device
         model = LatentDiffusionAudio(C.LDM_I2A, device=device, state_dict=ckpt_state_dict,
-                                     cond_stage_model=cond_stage_model, seeds=(4, 1))
+                                     cond_stage_model=cond_stage_model, seeds=(4, 1), precision=precision)
         self.sampler = DDIMSampler(model)
         self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=model.ctx)
 
@@ -126,10 +128,11 @@ class I2A:
 
 
 class Inpaint:
-    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, mel_transform=None):
+    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, mel_transform=None, precision=None):
         print("Initializing Make-An-Audio-inpaint to %s" % device)
         self.device = device
-        model = LatentDiffusionAudio(C.LDM_INPAINT, device=device, state_dict=ckpt_state_dict, seeds=(5, 1))
+        model = LatentDiffusionAudio(C.LDM_INPAINT, device=device, state_dict=ckpt_state_dict, seeds=(5, 1),
+                                     precision=precision)
         self.sampler = DDIMSampler(model)
         self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=model.ctx)
         self.mel_transform = mel_transform      # TRANSFORMS_16000 (extract_mel_spectrogram.py:140-150), pluggable

@@ -15,7 +15,7 @@ import yaml
 
 from .. import config as C
 from .. import weights as WT
-from ..backend import Context, Vocoder
+from ..backend import Context, Vocoder, default_precision
 
 VOCODERS = {}
 
@@ -57,12 +57,12 @@ class HifiGanGenerator(object):
     """Callable generator; weights arrive through load_state_dict (reference key layout, with or without
     weight-norm) or are seeded-random until then."""
 
-    def __init__(self, h, c_out=1, device="cuda:0", ctx=None, seed=2):
+    def __init__(self, h, c_out=1, device="cuda:0", ctx=None, seed=2, precision=None):
         if isinstance(h, dict) and h.get("use_pitch_embed"):
             raise NotImplementedError("NSF branch (use_pitch_embed) is a 'next' row, not on this path")
         self.h = h
         self.cfg = _cfg_from_h(h)
-        self.ctx = ctx or Context(device)
+        self.ctx = ctx or Context(device, precision=precision or default_precision())
         self.device = self.ctx.device
         self._sd = WT.make_vocoder_state_dict(self.cfg, seed=seed)
         self._impl = None
@@ -124,12 +124,12 @@ class _Gen(object):
 
 
 class VocoderHifigan(_VocodeMixin):
-    def __init__(self, ckpt_vocoder=None, device="cuda:0", ctx=None, args=None, seed=2):
+    def __init__(self, ckpt_vocoder=None, device="cuda:0", ctx=None, args=None, seed=2, precision=None):
         if args is None and ckpt_vocoder is not None and os.path.exists(os.path.join(ckpt_vocoder, "args.yml")):
             with open(os.path.join(ckpt_vocoder, "args.yml")) as f:
                 args = yaml.safe_load(f)
         self.cfg = _cfg_from_h(args, "hifigan") if args is not None else dict(C.HIFIGAN_16K)
-        self.ctx = ctx or Context(device)
+        self.ctx = ctx or Context(device, precision=precision or default_precision())
         self.device = self.ctx.device
         sd = None
         path = os.path.join(ckpt_vocoder, "best_netG.pt") if ckpt_vocoder else None
@@ -141,12 +141,12 @@ class VocoderHifigan(_VocodeMixin):
 
 
 class VocoderBigVGAN(_VocodeMixin):
-    def __init__(self, ckpt_vocoder=None, device="cuda:0", ctx=None, args=None, seed=3):
+    def __init__(self, ckpt_vocoder=None, device="cuda:0", ctx=None, args=None, seed=3, precision=None):
         if args is None and ckpt_vocoder is not None and os.path.exists(os.path.join(ckpt_vocoder, "args.yml")):
             with open(os.path.join(ckpt_vocoder, "args.yml")) as f:
                 args = yaml.safe_load(f)
         self.cfg = _cfg_from_h(args, "bigvgan") if args is not None else dict(C.BIGVGAN_16K)
-        self.ctx = ctx or Context(device)
+        self.ctx = ctx or Context(device, precision=precision or default_precision())
         self.device = self.ctx.device
         sd = None
         path = os.path.join(ckpt_vocoder, "best_netG.pt") if ckpt_vocoder else None
@@ -168,10 +168,10 @@ class BaseVocoder(object):
 class HifiGAN(BaseVocoder):
     """NeuralSeq/vocoders/hifigan.py:39-69: spec2wav(mel [T,80]) -> wav [T*hop] float32 ndarray."""
 
-    def __init__(self, hparams=None, device="cuda:0", ctx=None, state_dict=None):
+    def __init__(self, hparams=None, device="cuda:0", ctx=None, state_dict=None, precision=None):
         h = dict(hparams or C.HIFIGAN_NS_512)
         h.setdefault("use_pitch_embed", False)
-        self.model = HifiGanGenerator(h, device=device, ctx=ctx)
+        self.model = HifiGanGenerator(h, device=device, ctx=ctx, precision=precision)
         if state_dict is not None:
             self.model.load_state_dict(state_dict, strict=True)
         self.device = self.model.device

@@ -373,6 +373,69 @@ def bigvgan_case(name, cfg, T, manifest, seed=3):
     print(name, "wav std", float(wav.std()), "absmax", float(wav.abs().max()))
 
 
+def config2_case(name, rows=(0, 5), S=100, scale=1.5, n_batch=8):
+    """BASELINE configs[1] exactly as bench.py feeds it (8 prompts: x_T = RandomState(55).randn(8, 4, 10, 78), c =
+    layer-normed N(0,1) rows of generator 1234, one unconditional row of generator 1235, CFG 1.5, 100 DDIM steps),
+    for `rows` of that batch: the reference DDIMSampler over the reference UNetModel, then the reference VAE Decoder
+    and HiFi-GAN Generator (audio-chatgpt.py:160-181 with the hifi_0127 vocoder).  ~3 minutes on 8 cores."""
+    from argparse import Namespace
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.model import Decoder
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+    from vocoder.hifigan.modules import Generator
+    unet = unet_case("unet_t2a", C.UNET_T2A, 10, 78, 77, {}, save=False)
+
+    class Shim:
+        def __init__(self, ldm):
+            betas = make_beta_schedule("linear", ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+            ac = np.cumprod(1.0 - betas, axis=0)
+            self.num_timesteps = ldm["timesteps"]
+            self.betas = torch.tensor(betas, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+            self.device = torch.device("cpu")
+
+        def apply_model(self, x, t, c):
+            return unet(x, t, context=c)
+
+    sampler = DDIMSampler(Shim(C.LDM_T2A))
+    sampler.device = torch.device("cpu")
+    rows = list(rows)
+    x_T = torch.from_numpy(np.random.RandomState(55).randn(n_batch, 4, 10, 78)).float()[rows]
+    c = _cond(n_batch, 77, 1234)[rows]
+    uc = _cond(1, 77, 1235).expand(len(rows), -1, -1).contiguous()
+    with torch.no_grad():
+        z, _ = sampler.sample(S=S, conditioning=c, batch_size=len(rows), shape=[4, 10, 78], verbose=False,
+                              unconditional_guidance_scale=scale, unconditional_conditioning=uc, x_T=x_T)
+    dd = C.VAE_DDCONFIG
+    dec = Decoder(ch=dd["ch"], out_ch=dd["out_ch"], ch_mult=tuple(dd["ch_mult"]), num_res_blocks=dd["num_res_blocks"],
+                  attn_resolutions=list(dd["attn_resolutions"]), in_channels=dd["in_channels"],
+                  resolution=dd["resolution"], z_channels=dd["z_channels"], double_z=dd["double_z"]).eval()
+    vsd = WT.make_vae_state_dict(dd, seed=1)
+    dec.load_state_dict(WT.strip_prefix(vsd, "decoder."), strict=True)
+    pq = torch.nn.Conv2d(dd["embed_dim"], dd["z_channels"], 1)
+    pq.load_state_dict(WT.strip_prefix(vsd, "post_quant_conv."))
+    cfg = C.HIFIGAN_16K
+    gen = Generator(Namespace(**{k: (list(map(list, v)) if k == "resblock_dilation_sizes" else
+                                     (list(v) if isinstance(v, tuple) else v)) for k, v in cfg.items()})).eval()
+    gen.load_state_dict(WT.make_vocoder_state_dict(cfg, seed=2), strict=True)
+    with torch.no_grad():
+        spec = torch.clamp((dec(pq(z)) + 1.0) / 2.0, 0.0, 1.0)[:, 0]      # audio-chatgpt.py:175-176
+        wav = gen(spec)[:, 0]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), rows=np.asarray(rows), n_batch=n_batch, S=S, scale=scale,
+                        z=z.numpy(), spec=spec.numpy().astype(np.float32), wav=wav.numpy().astype(np.float32))
+    print(name, "z std", float(z.std()), "spec mean", float(spec.mean()), "wav std", float(wav.std()))
+
+
+def main_config2_only():
+    """`python tests/golden/make_golden.py config2`: the benchmark configuration's own golden + the 624-frame BigVGAN."""
+    torch.set_num_threads(8)
+    _install_shims()
+    config2_case("t2a_config2_s100")
+    bigvgan_case("bigvgan_16k_t624", C.BIGVGAN_16K, 624, {})
+    print("torch", torch.__version__)
+
+
 def main():
     torch.set_num_threads(8)
     _install_shims()
@@ -392,6 +455,8 @@ def main():
     bigvgan_case("bigvgan_16k", C.BIGVGAN_16K, 48, manifest)
     hifigan_nsf_case("hifigan_nsf_24k", C.HIFIGAN_NSF_24K, 40, manifest)
     diffsinger_case("diffsinger_ds1000", C.DIFFSINGER_DS1000, 48, manifest)
+    config2_case("t2a_config2_s100")
+    bigvgan_case("bigvgan_16k_t624", C.BIGVGAN_16K, 624, {})
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     print("torch", torch.__version__)
@@ -434,4 +499,5 @@ def main_ddim_variants_only():
 
 
 if __name__ == "__main__":
-    {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "diffsinger": main_diffsinger_only}.get(" ".join(sys.argv[1:]), main)()
+    {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "diffsinger": main_diffsinger_only,
+     "config2": main_config2_only}.get(" ".join(sys.argv[1:]), main)()

@@ -199,3 +199,27 @@ def test_diffsinger_denoiser_and_plms_loop_match_reference(golden):
     for i, x in enumerate(trace):
         _close(x.numpy(), g["x_inter"][i], 5e-5, f"plms step {i}")
     _close(x0.numpy(), g["x0"], 5e-5, "x0")
+
+
+def test_config2_decode_and_vocode_match_reference(golden):
+    """The benchmark configuration's golden (100-step latents of rows 0 and 5 of the 8-prompt batch, made by the
+    reference sampler): the oracle's VAE decode + clamp + HiFi-GAN from the reference latent reproduces the reference's
+    mel and waveform.  (The 100-step oracle trajectory itself costs minutes of CPU; the sampler is pinned at 10 steps
+    above, and the GPU test compares the HIP path's 100-step result with this golden.)"""
+    g = golden("t2a_config2_s100")
+    vsd = WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1, with_encoder=False)
+    gsd = O_voc.fold_weight_norm(WT.make_vocoder_state_dict(C.HIFIGAN_16K, seed=2))
+    z = torch.from_numpy(g["z"][:1])
+    with torch.no_grad():
+        spec = torch.clamp((O_vae.decode_first_stage(vsd, C.VAE_DDCONFIG, z, 1.0) + 1.0) / 2.0, 0.0, 1.0)[:, 0]
+        wav = O_voc.hifigan_forward(gsd, C.HIFIGAN_16K, spec)[:, 0]
+    _close(spec.numpy(), g["spec"][:1], 2e-5, "config2 mel")
+    _close(wav.numpy(), g["wav"][:1], 2e-5, "config2 wav")
+
+
+def test_bigvgan_624_frames_matches_reference(golden):
+    g = golden("bigvgan_16k_t624")
+    sd = O_voc.fold_weight_norm(WT.make_vocoder_state_dict(C.BIGVGAN_16K, seed=3))
+    with torch.no_grad():
+        wav = O_voc.bigvgan_forward(sd, C.BIGVGAN_16K, torch.from_numpy(g["mel"]))
+    _close(wav.numpy(), g["wav"], 2e-5, "bigvgan 624 frames")
