@@ -56,7 +56,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE>
+template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE, int PF>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm p, int ntiles, int tiles, int Nb,
                                                                      int cps, float* __restrict__ part) {
     constexpr int NW = WGM * WGN, NTH = 64 * NW;
@@ -66,10 +66,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
     constexpr int STAGE = ROWS * 128;                  // bytes
     constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // copies (8 rows x 128 B) per wave and chunk: A rows, B rows
     constexpr int IPW = AI + BI;
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "copy assignment");
+    // L2 prefetch (PF > 0): every chunk, each lane touches one 128-byte line of the tile rows of the chunk PF ahead with a
+    // 4-byte LDS-DMA into a scratch area (no VGPR is written, so nothing waits for it).  The copies of that chunk, issued
+    // PF - NS + 1 iterations later, then hit L2 instead of paying the MALL / HBM latency on the critical path: the LDS
+    // stages alone cannot hold the latency x bandwidth product (42 B/clk x ~2900 clk = 120 KB for 128x128 tiles).
+    constexpr int PFI = PF > 0 ? (ROWS + 64 * NW - 1) / (64 * NW) : 0;      // prefetch instructions per wave and chunk
+    constexpr int VMI = IPW + PFI;                                          // VM operations per wave and chunk
+    constexpr int VM_TAIL = PFI;        // prefetches issued after the copies of the same chunk (younger than them)
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0 && BM % 64 == 0, "copy assignment");
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % 32 == 0, "tile");
-    static_assert(NS >= (PIPE ? 3 : 2) && (NS - 2) * IPW <= 63, "stages / vmcnt field");
-    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NS][ROWS][128]
+    static_assert(NS >= (PIPE ? 3 : 2) && (NS - 2) * VMI + VM_TAIL <= 63, "stages / vmcnt field");
+    static_assert(PF == 0 || PF >= NS, "prefetch distance must exceed the copy queue");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NS][ROWS][128] (+ [NW][PFI][256] prefetch scratch)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -143,6 +151,76 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
         const int n = min(n0 + 8 * (j * NW + wid) + r8, Nb - 1);
         gpb[j] = reinterpret_cast<const char*>(p.b) + ((long long)n * p.ldb + (long long)c_begin * BK) * 4 + slot_b;
     }
+    // ---- prefetch lines: line 64 (q NW + wid) + lane of the list [A rows | B rows] of the tile
+    int pf_b[PFI > 0 ? PFI : 1], pf_iy0[PFI > 0 ? PFI : 1], pf_ix0[PFI > 0 ? PFI : 1];
+    const char* pfp[PFI > 0 ? PFI : 1];
+    unsigned pfinc[PFI > 0 ? PFI : 1];
+    int pf_c = c_begin + PF, pf_tap = 0, pf_ci = 0;
+    auto pf_set_tap = [&]() {
+        const int ky = pf_tap / p.KW, kx = pf_tap - ky * p.KW;
+#pragma unroll
+        for (int q = 0; q < PFI; ++q) {
+            if (64 * (q * NW + wid) < BM) {            // (wave-uniform)
+                int iy = pf_iy0[q] + ky * p.dh, ix = pf_ix0[q] + kx * p.dw;
+                const bool v = pf_b[q] >= 0 && iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim;
+                iy >>= p.up;
+                ix >>= p.up;
+                const long long pos = ((long long)pf_b[q] * p.Hin + iy) * p.Win + ix;
+                pfp[q] = v ? reinterpret_cast<const char*>(p.a1) + (pos * p.lda1 + pf_ci) * 4 : zero;
+                pfinc[q] = v ? BK * 4 : 0;
+            }
+        }
+    };
+    if constexpr (PFI > 0) {
+        pf_tap = pf_c / cpt;
+        pf_ci = (pf_c - pf_tap * cpt) * BK;
+#pragma unroll
+        for (int q = 0; q < PFI; ++q) {
+            const int li = 64 * (q * NW + wid) + lane;
+            pf_b[q] = -1;
+            pf_iy0[q] = pf_ix0[q] = 0;
+            pfp[q] = zero;
+            pfinc[q] = 0;
+            if (li < BM) {
+                const int m = m0 + li;
+                if (m < p.M) {
+                    const int b = m / rpb;
+                    const int rem = m - b * rpb;
+                    const int oy = rem / p.Wout;
+                    pf_b[q] = b;
+                    pf_iy0[q] = oy * p.sh - p.ph;
+                    pf_ix0[q] = (rem - oy * p.Wout) * p.sw - p.pw;
+                }
+            } else if (li < ROWS && pf_c < c_end) {
+                const int n = min(n0 + li - BM, Nb - 1);
+                pfp[q] = reinterpret_cast<const char*>(p.b) + ((long long)n * p.ldb + (long long)pf_c * BK) * 4;
+                pfinc[q] = BK * 4;
+            }
+        }
+        if (pf_c < c_end) pf_set_tap();
+    }
+    auto prefetch = [&]() {
+        if constexpr (PFI > 0) {
+            static_for<0, PFI>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                __builtin_amdgcn_global_load_lds((gptr_t)pfp[q], (lptr_t)(smem + NS * STAGE + (wid * PFI + q) * 256), 4, 0, 0);
+                pfp[q] += pfinc[q];
+            });
+            ++pf_c;
+            pf_ci += BK;
+            if (pf_c >= c_end) {
+#pragma unroll
+                for (int q = 0; q < PFI; ++q) {
+                    pfp[q] = zero;
+                    pfinc[q] = 0;
+                }
+            } else if (pf_ci >= Ctot) {
+                pf_ci = 0;
+                ++pf_tap;
+                pf_set_tap();
+            }
+        }
+    };
     int g_tap = c_begin / cpt, g_ci = (c_begin - g_tap * cpt) * BK, g_c = c_begin;
     auto kill = [&]() {           // chunks past the slice: copies still issue (uniform vmcnt arithmetic), from the zero page
 #pragma unroll
@@ -181,6 +259,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
     auto issue = [&](int st) {
         static_for<0, IPW>([&](auto jc) { copy1(st, jc); });
         advance();
+        prefetch();
     };
 
     f32x16 acc[MI][NI];
@@ -244,7 +323,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
         for (int s = 0; s < NS - 1; ++s) issue(s);
         int st = 0, st_fill = NS - 1;
         for (int c = 0; c < nloc; ++c) {
-            wait_vmcnt<(NS - 2) * IPW>();
+            wait_vmcnt<(NS - 2) * VMI + VM_TAIL>();
             __builtin_amdgcn_s_barrier();
             if (!(p.dbg & 2)) issue(st_fill);
             if (!(p.dbg & 1)) {
@@ -268,7 +347,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
         //          last reads fed the MFMAs of P2(c-1) -- before it reached B(c+1)).
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s) issue(s);
-        wait_vmcnt<(NS - 2) * IPW>();
+        wait_vmcnt<(NS - 2) * VMI + VM_TAIL>();
         __builtin_amdgcn_s_barrier();              // chunk 0 is in LDS
         Frags f0, f1;
         read_frags(smem, 0, f0);
@@ -281,7 +360,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
             __builtin_amdgcn_sched_barrier(0);
             mma(f0);
             __builtin_amdgcn_sched_barrier(0);
-            wait_vmcnt<(NS - 3) * IPW>();          // this wave's copies of chunk c+1 have landed
+            wait_vmcnt<(NS - 3) * VMI + VM_TAIL>();    // this wave's copies of chunk c+1 have landed
             __builtin_amdgcn_s_barrier();          // B(c+1): everybody's have, and everybody consumed chunk c-1
             read_frags(smem + st_next * STAGE, 0, f0);      // (past the last chunk: zeros, never multiplied)
             __builtin_amdgcn_sched_barrier(0);
@@ -300,6 +379,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
                 __builtin_amdgcn_sched_barrier(0);
             });
             advance();
+            prefetch();
             st = st_next;
         }
     }
@@ -359,9 +439,10 @@ __global__ void splitk_reduce_kernel(const IGemm p, const float* __restrict__ pa
     igemm_epilogue<1, JW>(p, acc, mt * BM + wm * WTM + i * 32, nt * BN + wn * WTN + j * 32, lane & 31, lane >> 5, 0, Nb, rpb);
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE>
+template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE, int PF>
 void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
-    constexpr int NTH = 64 * WGM * WGN;
+    constexpr int NW = WGM * WGN, NTH = 64 * NW;
+    constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
     const int ncols = p.N * (p.geglu ? 2 : 1);
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (ncols + BN - 1) / BN;
     const int tiles = mtiles * ntiles;
@@ -369,8 +450,11 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
     const int cps = (nchunks + S - 1) / S;
     const int Seff = (nchunks + cps - 1) / cps;            // slices that have at least one chunk
     MAA_CHECK(Seff == S, "split-K plan leaves an empty slice");
-    constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
-    auto kern = igemm_dma2_kernel<BM, BN, WGM, WGN, NS, PIPE>;
+    MAA_CHECK(!p.geglu || NI % 2 == 0, "GEGLU needs value / gate block pairs inside a wave");
+    constexpr int PFI = PF > 0 ? (BM + BN + 64 * NW - 1) / (64 * NW) : 0;
+    constexpr size_t lds = (size_t)NS * (BM + BN) * 128 + (size_t)NW * PFI * 256;
+    static_assert(lds <= 163840, "LDS per workgroup");
+    auto kern = igemm_dma2_kernel<BM, BN, WGM, WGN, NS, PIPE, PF>;
     static bool attr_set = false;
     if (!attr_set) {
         MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -379,15 +463,15 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
     hipLaunchKernelGGL(kern, dim3((unsigned)((long long)tiles * S)), dim3(NTH), lds, ctx.stream, p, ntiles, tiles, Nb, cps,
                        S > 1 ? part : nullptr);
     if (S > 1) {
-        constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
-        if (p.geglu) {
-            static_assert(NI % 2 == 0, "GEGLU pairs");
-            hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)(tiles * MI * (NI / 2))), dim3(NTH), 0, ctx.stream, p, part,
-                               S, tiles, ntiles, Nb, BM, BN, WGN, MI, NI);
-        } else {
-            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)(tiles * MI * NI)), dim3(NTH), 0, ctx.stream, p, part, S,
-                               tiles, ntiles, Nb, BM, BN, WGN, MI, NI);
+        if constexpr (NI % 2 == 0) {
+            if (p.geglu) {
+                hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)(tiles * MI * (NI / 2))), dim3(NTH), 0, ctx.stream, p,
+                                   part, S, tiles, ntiles, Nb, BM, BN, WGN, MI, NI);
+                return;
+            }
         }
+        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)(tiles * MI * NI)), dim3(NTH), 0, ctx.stream, p, part, S, tiles,
+                           ntiles, Nb, BM, BN, WGN, MI, NI);
     }
 }
 
@@ -404,21 +488,26 @@ int fit_slices(int nchunks, int S) {
 }
 
 // Which problems take this engine, with which tile and how many K slices: a function of the layer (K, packed N) only.
-// MAA_DMA2 = "off" | "cfg,ns,pipe,S[,kmin]" overrides the policy (tuning and tests; read on every launch).
+// MAA_DMA2 = "off" | "cfg,ns,pipe,S[,kmin[,pf]]" overrides the policy (tuning and tests; read on every launch).
 Dma2Plan plan_impl(const IGemm& p) {
     Dma2Plan pl;
     const int ncols = p.N * (p.geglu ? 2 : 1);
     const int nchunks = p.K / BK;
-    const char* env = std::getenv("MAA_DMA2");
+    // MAA_DMA2_N<packed N> (e.g. MAA_DMA2_N320) overrides MAA_DMA2 for the layers of that width
+    char var[32];
+    std::snprintf(var, sizeof(var), "MAA_DMA2_N%d", ncols);
+    const char* env = std::getenv(var);
+    if (!env || !*env) env = std::getenv("MAA_DMA2");
     if (env && *env) {
         if (!std::strcmp(env, "off")) return pl;
-        int cfg = 0, ns = 2, pipe = 0, S = 1, kmin = 0;
-        const int k = std::sscanf(env, "%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin);
+        int cfg = 0, ns = 2, pipe = 0, S = 1, kmin = 0, pf = 0;
+        const int k = std::sscanf(env, "%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &pf);
         if (k >= 4) {
-            if (p.K < kmin) return pl;
+            if (p.K < kmin || (p.geglu && cfg == 2)) return pl;
             pl.cfg = cfg;
             pl.ns = ns;
             pl.pipe = pipe;
+            pl.pf = pf;
             pl.S = fit_slices(nchunks, S);
             return pl;
         }
@@ -439,14 +528,16 @@ Dma2Plan igemm_dma2_plan(const IGemm& p) { return plan_impl(p); }
 size_t igemm_dma2_workspace_floats(const IGemm& p, const Dma2Plan& pl) {
     if (pl.cfg < 0 || pl.S <= 1) return 0;
     const int ncols = p.N * (p.geglu ? 2 : 1);
-    const int BM = pl.cfg == 1 ? 256 : 128, BN = 128;
+    const int BM = pl.cfg == 1 ? 256 : 128, BN = pl.cfg == 2 ? 320 : 128;
     const long long tiles = (long long)((p.M + BM - 1) / BM) * ((ncols + BN - 1) / BN);
     return (size_t)(tiles * pl.S * BM * BN);
 }
 
 const char* igemm_dma2_name(const Dma2Plan& pl) {
-    return pl.cfg == 1 ? (pl.S > 1 ? "igemm_dma2_bf16x3<256x128,splitK>" : "igemm_dma2_bf16x3<256x128>")
-                       : (pl.S > 1 ? "igemm_dma2_bf16x3<128x128,splitK>" : "igemm_dma2_bf16x3<128x128>");
+    static const char* names[3][2] = {{"igemm_dma2_bf16x3<128x128>", "igemm_dma2_bf16x3<128x128,splitK>"},
+                                      {"igemm_dma2_bf16x3<256x128>", "igemm_dma2_bf16x3<256x128,splitK>"},
+                                      {"igemm_dma2_bf16x3<128x320>", "igemm_dma2_bf16x3<128x320,splitK>"}};
+    return names[pl.cfg < 0 || pl.cfg > 2 ? 0 : pl.cfg][pl.S > 1];
 }
 
 // The caller has checked the split32 conditions (both operands split, single source, C % 32 == 0, K % 32 == 0, 16-byte
@@ -454,16 +545,29 @@ const char* igemm_dma2_name(const Dma2Plan& pl) {
 void launch_igemm_dma2(const Ctx& ctx, const IGemm& p, int Nb, const Dma2Plan& pl, float* part) {
     MAA_CHECK(pl.cfg >= 0, "igemm_dma2: problem not planned for this engine");
     MAA_CHECK(pl.S == 1 || part != nullptr, "igemm_dma2: split-K needs its slab workspace");
-    const int key = pl.cfg * 100 + pl.ns * 10 + pl.pipe;
+    constexpr int D = 6;        // prefetch distance in chunks when the plan asks for L2 prefetch
+    const int key = pl.cfg * 1000 + pl.ns * 100 + pl.pipe * 10 + (pl.pf ? 1 : 0);
     switch (key) {
-        case 20: launch_one<128, 128, 2, 2, 2, false>(ctx, p, Nb, pl.S, part); break;
-        case 30: launch_one<128, 128, 2, 2, 3, false>(ctx, p, Nb, pl.S, part); break;
-        case 31: launch_one<128, 128, 2, 2, 3, true>(ctx, p, Nb, pl.S, part); break;
-        case 41: launch_one<128, 128, 2, 2, 4, true>(ctx, p, Nb, pl.S, part); break;
-        case 120: launch_one<256, 128, 4, 2, 2, false>(ctx, p, Nb, pl.S, part); break;
-        case 130: launch_one<256, 128, 4, 2, 3, false>(ctx, p, Nb, pl.S, part); break;
-        case 131: launch_one<256, 128, 4, 2, 3, true>(ctx, p, Nb, pl.S, part); break;
-        default: MAA_CHECK(false, "igemm_dma2: no such (tile, stages, pipe) instantiation");
+        // 128x128 tiles, 4 waves of 64x64
+        case 200: launch_one<128, 128, 2, 2, 2, false, 0>(ctx, p, Nb, pl.S, part); break;
+        case 201: launch_one<128, 128, 2, 2, 2, false, D>(ctx, p, Nb, pl.S, part); break;
+        case 300: launch_one<128, 128, 2, 2, 3, false, 0>(ctx, p, Nb, pl.S, part); break;
+        case 301: launch_one<128, 128, 2, 2, 3, false, D>(ctx, p, Nb, pl.S, part); break;
+        case 401: launch_one<128, 128, 2, 2, 4, false, D>(ctx, p, Nb, pl.S, part); break;
+        case 310: launch_one<128, 128, 2, 2, 3, true, 0>(ctx, p, Nb, pl.S, part); break;
+        case 410: launch_one<128, 128, 2, 2, 4, true, 0>(ctx, p, Nb, pl.S, part); break;
+        case 411: launch_one<128, 128, 2, 2, 4, true, D>(ctx, p, Nb, pl.S, part); break;
+        case 510: launch_one<128, 128, 2, 2, 5, true, 0>(ctx, p, Nb, pl.S, part); break;
+        // 256x128 tiles, 8 waves of 64x64
+        case 1200: launch_one<256, 128, 4, 2, 2, false, 0>(ctx, p, Nb, pl.S, part); break;
+        case 1201: launch_one<256, 128, 4, 2, 2, false, D>(ctx, p, Nb, pl.S, part); break;
+        case 1300: launch_one<256, 128, 4, 2, 3, false, 0>(ctx, p, Nb, pl.S, part); break;
+        case 1310: launch_one<256, 128, 4, 2, 3, true, 0>(ctx, p, Nb, pl.S, part); break;
+        case 1311: launch_one<256, 128, 4, 2, 3, true, D>(ctx, p, Nb, pl.S, part); break;
+        // 128x320 tiles (all of N = 320 in one tile), 8 waves of 32x160
+        case 2200: launch_one<128, 320, 4, 2, 2, false, 0>(ctx, p, Nb, pl.S, part); break;
+        case 2201: launch_one<128, 320, 4, 2, 2, false, D>(ctx, p, Nb, pl.S, part); break;
+        default: MAA_CHECK(false, "igemm_dma2: no such (tile, stages, pipe, prefetch) instantiation");
     }
 }
 

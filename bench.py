@@ -13,6 +13,11 @@ With N > 1 (BASELINE configs[3]) each rank owns 8 different prompts (weak scalin
 conditioning for all ranks and broadcasts it over RCCL, waveforms are gathered to rank 0; no collective runs
 inside the DDIM loop.
 
+Secondary workloads (reported under "secondary" in the same JSON line at N = 1, or alone with --workload):
+  hifigan64 -- BASELINE configs[2]: NeuralSeq HiFi-GAN (22.05 kHz, upsample_initial_channel 512), mel [64, 80, 1024]
+               (clip(N(-2.25, 1.5), -6, 1.5), seed 7) -> wave [64, 262144] = 760.9 audio-seconds per step, mel resident
+               in HBM; roofline of its dominant kernel and of the whole pass against the 40.24 TFLOP it computes.
+
 Output: ONE JSON line on rank 0 with metric/value plus
   roofline     -- the dominant kernel (the implicit-GEMM engine): algorithmic FLOPs (2*M*N*K) of its launches / their
                   summed hipEvent durations, against the dense MFMA peak of the precision mode (157.3 TFLOP/s fp32,
@@ -93,6 +98,101 @@ def cpu_baseline(ddim_steps_sample=2):
                        % (ddim_steps_sample, DDIM_STEPS, t_unet, t_vae, t_voc, torch.__version__, cores))
 
 
+HIFIGAN64 = dict(B=64, T=1024, seed=7)
+
+
+def hifigan64_mel(B=HIFIGAN64["B"], T=HIFIGAN64["T"], seed=HIFIGAN64["seed"]):
+    """BASELINE.md section 2, config 3 (the same formula as tests/golden/make_golden.py hifigan_case)."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.clamp(torch.randn(B, 80, T, generator=g) * 1.5 - 2.25, -6.0, 1.5)
+
+
+def roofline_of(rows, precision):
+    """Roofline object of the dominant implicit-GEMM kernel out of a maa_prof table (hipEvents on the library's stream)."""
+    total_ms = sum(r["ms"] for r in rows.values())
+    ig = {k: v for k, v in rows.items() if k.startswith("igemm")}
+    dom = max(ig, key=lambda k: ig[k]["ms"])
+    ig_ms = sum(v["ms"] for v in ig.values())
+    ig_fl = sum(v["flops"] for v in ig.values())
+    d = ig[dom]
+    peak = PEAK_TFLOPS[precision]
+    per = MFMA_PER_FLOP[precision] if "bf16" in dom else 1
+    if "f32" in dom:
+        peak = PEAK_TFLOPS["f32"]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "kernel": dom,
+        "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+        "mfma_ops_per_algorithmic_flop": per, "frac_of_mfma_issue_peak": ach * per / peak,
+        "traffic": None, "traffic_note": None,
+        "launches": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"],
+        "flops_per_launch_avg": d["flops"] / d["launches"],
+        "all_igemm": {"achieved": ig_fl / (ig_ms * 1e-3) / 1e12, "ms": ig_ms, "tflop": ig_fl / 1e12,
+                      "share_of_kernel_time": ig_ms / total_ms},
+        "kernel_time_ms": {k: round(v["ms"], 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])},
+    }
+
+
+def run_hifigan64(dev, precision, steps, warmup, cpu_base=True, roofline=True):
+    """BASELINE configs[2] on one GPU.  A step = one generator pass over the [64, 80, 1024] mel batch resident in HBM."""
+    from audiogpt_amd.backend import Context, Vocoder
+    cfg = C.HIFIGAN_NS_512
+    ctx = Context(dev, precision=precision)
+    voc = Vocoder(ctx, cfg, WT.make_vocoder_state_dict(cfg, seed=2))
+    mel = hifigan64_mel().to(dev)
+    B, T = mel.shape[0], mel.shape[2]
+    for _ in range(warmup):
+        voc(mel)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wav = voc(mel)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert wav.shape[-1] == T * voc.hop
+    audio_s = B * T * voc.hop / float(cfg["sampling_rate"])
+    res = {"metric": "vocoded audio-seconds/sec (HiFi-GAN 22.05 kHz, 64 x 1024 frames)", "value": audio_s * steps / elapsed,
+           "unit": "audio-seconds/sec", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+           "higher_is_better": True, "dtype": precision, "data": "synthetic mel clip(N(-2.25,1.5),-6,1.5) seed 7; seeded random-init weights",
+           "config": {"workload": "NeuralSeq HiFi-GAN generator only, upsample_initial_channel 512, batch 64 x 1024 frames -> 64 x 262144 samples",
+                      "audio_seconds_per_step": audio_s}}
+    if roofline:
+        ctx.prof_begin()
+        voc(mel)
+        rows = ctx.prof_end()
+        r = roofline_of(rows, precision)
+        # the pass as a whole: SURVEY 8(d) prices it at 0.6288 TFLOP per 1024-frame item and, in fp32 storage, at
+        # 218 MB per item of stage-boundary bytes (the fused ideal) / 4.15 GB per item layer by layer
+        total_ms = sum(v["ms"] for v in rows.values())
+        r["whole_pass"] = {"tflop": 0.6288 * B, "achieved_tflops": 0.6288 * B / (total_ms * 1e-3),
+                           "frac_of_mfma_peak": 0.6288 * B / (total_ms * 1e-3) / r["peak"],
+                           "kernel_ms": total_ms,
+                           "hbm_gbs_if_layer_by_layer": 4.15 * B / (total_ms * 1e-3), "hbm_gbs_if_fused_ideal": 0.218 * B / (total_ms * 1e-3),
+                           "hbm_peak_gbs": 8000.0}
+        res["roofline"] = r
+    if cpu_base:
+        from oracle import vocoder as O_voc
+        cores = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(cores)
+        gsd = O_voc.fold_weight_norm(WT.make_vocoder_state_dict(cfg, seed=2))
+        m1 = mel[:1].cpu()
+        with torch.no_grad():
+            O_voc.hifigan_forward(gsd, cfg, m1[:, :, :64])
+            t0 = time.perf_counter()
+            n_items = 0
+            while time.perf_counter() - t0 < 10.0:
+                O_voc.hifigan_forward(gsd, cfg, m1)
+                n_items += 1
+            dt = time.perf_counter() - t0
+        res["cpu_baseline"] = dict(value=n_items * T * voc.hop / float(cfg["sampling_rate"]) / dt, unit="audio-seconds/sec",
+                                   cores=cores, kind="port",
+                                   sample="%d item(s) of 1024 frames through the CPU oracle (%.2f s each); torch %s fp32, %d threads"
+                                          % (n_items, dt / n_items, torch.__version__, cores))
+    voc.close()
+    ctx.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,6 +206,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table of one profiled batch to stderr")
+    ap.add_argument("--workload", default="t2a", choices=["t2a", "hifigan64"],
+                    help="t2a: BASELINE configs[1] (the headline line, with the others under 'secondary'); hifigan64: configs[2] alone")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the default run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +218,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload == "hifigan64":
+        assert world == 1, "the vocoder-only workload is a single-GPU configuration"
+        print(json.dumps(run_hifigan64(dev, args.precision, args.steps, args.warmup, not args.no_cpu_baseline,
+                                       not args.no_roofline)), flush=True)
+        return
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -122,7 +230,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from audiogpt_amd.pipeline import MakeAnAudio
-    from audiogpt_amd.shard import broadcast_conditioning, gather_waveforms
+    from audiogpt_amd.shard import broadcast_conditioning, gather_waveforms, start_codes
     pipe = MakeAnAudio(dev, precision=args.precision)
     n = args.prompts_per_gpu
     S = args.ddim_steps
@@ -135,11 +243,15 @@ def main():
     else:
         c_all, uc_row = None, None
 
+    # C0: every rank regenerates the start codes of the whole job and keeps its block (nothing is sent); done once,
+    # outside the timed loop, like the batch geometry every rank knows up front (no host round trips per batch)
+    x_T = start_codes(55, n * world, LATENT, world, rank).to(dev)
+    cond_shape, counts = (n * world, 77, 1024), [n] * world
+
     def one_batch():
-        c, uc = broadcast_conditioning(c_all, uc_row, n, dev, dist)          # C1: RCCL broadcast (no-op at N = 1)
-        x_T = torch.from_numpy(np.random.RandomState(55).randn(n * world, *LATENT)[rank * n:(rank + 1) * n]).float().to(dev)
+        c, uc = broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape)   # C1: RCCL broadcast (no-op at N = 1)
         wav, spec, z = pipe.generate(x_T, c, uc, CFG_SCALE, S, use_graph=use_graph)
-        return gather_waveforms(wav, dist)                                   # C2: gather to rank 0
+        return gather_waveforms(wav, dist, counts=counts)                    # C2: gather to rank 0
 
     def barrier():
         if dist is not None:
@@ -177,47 +289,32 @@ def main():
     if rank == 0 and not args.no_roofline:
         # one more batch, eager (graph launches cannot be event-timed), every kernel bracketed by hipEvents on the
         # library's stream; the dominant kernel family is the implicit-GEMM engine of the precision mode
-        x_T = torch.from_numpy(np.random.RandomState(55).randn(n, *LATENT)).float().to(dev)
         c = c_all[:n]
         uc = uc_row.expand(n, -1, -1).contiguous()
         pipe.ctx.prof_begin()
         pipe.generate(x_T, c, uc, CFG_SCALE, S, use_graph=False)
         rows = pipe.ctx.prof_end()
-        total_ms = sum(r["ms"] for r in rows.values())
-        ig = {k: v for k, v in rows.items() if k.startswith("igemm")}
-        dom = max(ig, key=lambda k: ig[k]["ms"])
-        ig_ms = sum(v["ms"] for v in ig.values())
-        ig_fl = sum(v["flops"] for v in ig.values())
-        d = ig[dom]
-        peak = PEAK_TFLOPS[args.precision]
-        per = MFMA_PER_FLOP[args.precision] if "bf16" in dom else 1
-        if "f32" in dom:
-            peak = PEAK_TFLOPS["f32"]
-        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        traffic, traffic_note = None, None
-        tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        result["roofline"] = roofline_of(rows, args.precision)
+        dom = result["roofline"]["kernel"]
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 t = json.load(f)
-            if t.get("precision") == args.precision and t.get("kernel_family") == dom.split("<")[0]:
-                traffic, traffic_note = t["hbm_bytes_per_launch"], t["note"]
-        result["roofline"] = {
-            "bound": "mfma", "kernel": dom,
-            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-            "mfma_ops_per_algorithmic_flop": per, "frac_of_mfma_issue_peak": ach * per / peak,
-            "traffic": traffic, "traffic_note": traffic_note,
-            "launches": d["launches"], "avg_launch_us": 1e3 * d["ms"] / d["launches"],
-            "flops_per_launch_avg": d["flops"] / d["launches"],
-            "all_igemm": {"achieved": ig_fl / (ig_ms * 1e-3) / 1e12, "ms": ig_ms, "tflop": ig_fl / 1e12,
-                          "share_of_kernel_time": ig_ms / total_ms},
-            "kernel_time_ms": {k: round(v["ms"], 3) for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"])},
-        }
+            # a measurement of THIS binary's launch mix only: same precision, same dominant kernel, same launches per batch
+            if t.get("precision") == args.precision and t.get("kernel") == dom and t.get("launches_per_batch") == result["roofline"]["launches"]:
+                result["roofline"]["traffic"], result["roofline"]["traffic_note"] = t["hbm_bytes_per_launch"], t["note"]
         if args.breakdown:
             for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
                 sys.stderr.write("%-28s launches %6d  ms %10.3f  TFLOP/s %8.2f  GB/s %9.1f\n" % (
                     k, v["launches"], v["ms"], v["flops"] / max(v["ms"], 1e-9) / 1e9, v["bytes"] / max(v["ms"], 1e-9) / 1e6))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (bounded sample, ~25 s of host time)
         result["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and world == 1 and not args.no_secondary:
+        pipe.close()
+        try:
+            result["secondary"] = {"hifigan64": run_hifigan64(dev, args.precision, 3, 1, not args.no_cpu_baseline, not args.no_roofline)}
+        except Exception as e:      # never lose the headline line to a secondary workload
+            result["secondary"] = {"hifigan64": {"error": str(e)[:300]}}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -427,6 +427,33 @@ def config2_case(name, rows=(0, 5), S=100, scale=1.5, n_batch=8):
     print(name, "z std", float(z.std()), "spec mean", float(spec.mean()), "wav std", float(wav.std()))
 
 
+def config3_case(name, cfg, row, B=64, T=1024, seed=2):
+    """BASELINE configs[2] input (mel [64, 80, 1024] = clip(N(-2.25, 1.5), -6, 1.5), generator seed 7, the formula of
+    hifigan_case): ONE row of the batch through the reference NeuralSeq HifiGanGenerator (the full 64-row output is
+    67 MB).  The mel is regenerated from the seed by the test; only the row's waveform is stored."""
+    NSGen = _ns_generator_cls()
+    h = {k: (list(map(list, v)) if k == "resblock_dilation_sizes" else (list(v) if isinstance(v, tuple) else v))
+         for k, v in cfg.items()}
+    h["use_pitch_embed"] = False
+    ns = NSGen(h).eval()
+    ns.load_state_dict(WT.make_vocoder_state_dict(cfg, seed=seed), strict=True)
+    g = torch.Generator().manual_seed(7)
+    mel = torch.clamp(torch.randn(B, 80, T, generator=g) * 1.5 - 2.25, -6.0, 1.5)
+    with torch.no_grad():
+        wav = ns(mel[row:row + 1])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), row=row, B=B, T=T, mel_seed=7, wav=wav.numpy().astype(np.float32))
+    print(name, "wav std", float(wav.std()), "absmax", float(wav.abs().max()))
+
+
+def main_config3_only():
+    """`python tests/golden/make_golden.py config3`"""
+    torch.set_num_threads(8)
+    _install_shims()
+    config3_case("hifigan_ns512_cfg3_row63", C.HIFIGAN_NS_512, 63)
+    config3_case("hifigan_ns128_cfg3_row0", C.HIFIGAN_NS_128, 0)
+    print("torch", torch.__version__)
+
+
 def main_config2_only():
     """`python tests/golden/make_golden.py config2`: the benchmark configuration's own golden + the 624-frame BigVGAN."""
     torch.set_num_threads(8)
@@ -457,6 +484,8 @@ def main():
     diffsinger_case("diffsinger_ds1000", C.DIFFSINGER_DS1000, 48, manifest)
     config2_case("t2a_config2_s100")
     bigvgan_case("bigvgan_16k_t624", C.BIGVGAN_16K, 624, {})
+    config3_case("hifigan_ns512_cfg3_row63", C.HIFIGAN_NS_512, 63)
+    config3_case("hifigan_ns128_cfg3_row0", C.HIFIGAN_NS_128, 0)
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     print("torch", torch.__version__)
@@ -500,4 +529,4 @@ def main_ddim_variants_only():
 
 if __name__ == "__main__":
     {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "diffsinger": main_diffsinger_only,
-     "config2": main_config2_only}.get(" ".join(sys.argv[1:]), main)()
+     "config2": main_config2_only, "config3": main_config3_only}.get(" ".join(sys.argv[1:]), main)()

@@ -17,8 +17,11 @@ from tests.util import check
 pytestmark = pytest.mark.gpu
 
 TOL = 2e-4
-# cfg (0: 128x128 / 4 waves, 1: 256x128 / 8 waves), LDS stages, in-wave pipelining, K slices
-VARIANTS = ["0,2,0,1", "0,2,0,4", "0,3,0,3", "0,3,1,2", "0,4,1,5", "1,2,0,2", "1,3,0,1", "1,3,1,3"]
+# cfg (0: 128x128 / 4 waves, 1: 256x128 / 8 waves, 2: 128x320 / 8 waves), LDS stages, in-wave pipelining, K slices
+# [, minimum K, L2 prefetch]
+VARIANTS = ["0,2,0,1", "0,2,0,4", "0,3,0,3", "0,3,1,2", "0,4,1,5", "1,2,0,2", "1,3,0,1", "1,3,1,3",
+            "0,2,0,4,0,1", "0,3,0,2,0,1", "0,4,0,3,0,1", "0,4,1,2,0,1", "0,5,1,2", "1,2,0,3,0,1", "1,3,1,2,0,1",
+            "2,2,0,1", "2,2,0,3,0,1"]
 
 
 @pytest.fixture(scope="module")
@@ -101,13 +104,14 @@ def test_identity_asymmetric(ctx):
     K = N = 256
     a = torch.eye(K)
     w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 17.0 + torch.arange(N)[:, None] * 0.5
-    for variant in ("0,2,0,1", "0,2,0,4", "1,3,1,2"):
+    for variant in ("0,2,0,1", "0,2,0,4", "1,3,1,2", "2,2,0,2,0,1", "0,4,1,2,0,1"):
         with forced(variant):
             y = ctx.op_linear(a, w)
         check(f"dma2[{variant}]_identity", y, w.t().contiguous(), TOL)
 
 
-@pytest.mark.parametrize("variant", ["0,2,0,1", "0,3,0,1", "0,3,1,1", "0,4,1,1", "1,2,0,1", "1,3,1,1"])
+@pytest.mark.parametrize("variant", ["0,2,0,1", "0,3,0,1", "0,3,1,1", "0,4,1,1", "1,2,0,1", "1,3,1,1", "0,2,0,1,0,1",
+                                     "0,4,1,1,0,1", "0,5,1,1", "2,2,0,1", "2,2,0,1,0,1"])
 def test_one_slice_is_bit_identical_to_the_other_engines(ctx, variant):
     """Same products in the same order per accumulator: without a K split this engine, the 64x64 LDS-DMA engine and the
     register-staged engine agree bit for bit."""
@@ -124,7 +128,7 @@ def test_one_slice_is_bit_identical_to_the_other_engines(ctx, variant):
     assert torch.equal(y, y_reg)
 
 
-@pytest.mark.parametrize("variant", ["0,2,0,4", "1,3,1,3", None])
+@pytest.mark.parametrize("variant", ["0,2,0,4", "1,3,1,3", "2,2,0,2,0,1", "0,4,1,2,0,1", None])
 def test_split_k_is_deterministic_and_batch_invariant(ctx, variant):
     """Slices are added in slice order by a separate kernel and their number depends on the layer only: repeated runs
     are bit-identical, and a sample's rows do not change with the batch they are computed in (None = default policy)."""

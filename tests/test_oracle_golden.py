@@ -223,3 +223,17 @@ def test_bigvgan_624_frames_matches_reference(golden):
     with torch.no_grad():
         wav = O_voc.bigvgan_forward(sd, C.BIGVGAN_16K, torch.from_numpy(g["mel"]))
     _close(wav.numpy(), g["wav"], 2e-5, "bigvgan 624 frames")
+
+
+@pytest.mark.parametrize("name,cfg", [("hifigan_ns512_cfg3_row63", C.HIFIGAN_NS_512), ("hifigan_ns128_cfg3_row0", C.HIFIGAN_NS_128)])
+def test_hifigan_config3_row_matches_reference(golden, name, cfg):
+    """BASELINE configs[2] shape (1024 frames, the seed-7 mel batch): one row through the oracle vs the reference's
+    NeuralSeq generator."""
+    from bench import hifigan64_mel
+    g = golden(name)
+    row = int(g["row"])
+    mel = hifigan64_mel(int(g["B"]), int(g["T"]), int(g["mel_seed"]))[row:row + 1]
+    sd = O_voc.fold_weight_norm(WT.make_vocoder_state_dict(cfg, seed=2))
+    with torch.no_grad():
+        wav = O_voc.hifigan_forward(sd, cfg, mel)
+    _close(wav.numpy(), g["wav"], 2e-6, name)

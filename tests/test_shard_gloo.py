@@ -32,7 +32,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, out_path):
+def _worker(rank, world, port, n_total, out_path, known=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -45,10 +45,13 @@ def _worker(rank, world, port, n_total, out_path):
         uc_row = torch.randn(1, 7, 16, generator=g)
     else:
         c_all, uc_row = None, None
-    c, uc = shard.broadcast_conditioning(c_all, uc_row, hi - lo, dev, dist)
+    # known = the batch geometry is agreed up front (bench.py's timed loop): no metadata / count exchange
+    shape = (n_total, 7, 16) if known else None
+    counts = [b - a for a, b in (shard.shard_range(n_total, world, r) for r in range(world))] if known else None
+    c, uc = shard.broadcast_conditioning(c_all, uc_row, hi - lo, dev, dist, shape=shape)
     x_T = shard.start_codes(55, n_total, (4, 2, 3), world, rank)
     wav = _fake_generate(x_T, c, uc)
-    full = shard.gather_waveforms(wav, dist)
+    full = shard.gather_waveforms(wav, dist, counts=counts)
     if rank == 0:
         np.save(out_path, full.numpy())
     else:
@@ -57,10 +60,10 @@ def _worker(rank, world, port, n_total, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [8, 5])
-def test_sharded_equals_single_process(tmp_path, n_total):
+@pytest.mark.parametrize("n_total,known", [(8, False), (5, False), (8, True), (5, True)])
+def test_sharded_equals_single_process(tmp_path, n_total, known):
     out = str(tmp_path / "wav.npy")
-    mp.spawn(_worker, args=(2, _free_port(), n_total, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), n_total, out, known), nprocs=2, join=True)
     got = np.load(out)
     g = torch.Generator().manual_seed(1234)
     c_all = torch.randn(n_total, 7, 16, generator=g)
