@@ -56,7 +56,8 @@ class maa_vocoder_config(C.Structure):
                 ("n_upsamples", C.c_int), ("upsample_rates", C.c_int * 8), ("upsample_kernel_sizes", C.c_int * 8),
                 ("n_kernels", C.c_int), ("resblock_kernel_sizes", C.c_int * 8),
                 ("n_dilations", C.c_int), ("resblock_dilation_sizes", (C.c_int * 8) * 8),
-                ("snake_beta", C.c_int), ("snake_logscale", C.c_int)]
+                ("snake_beta", C.c_int), ("snake_logscale", C.c_int),
+                ("use_pitch_embed", C.c_int), ("sampling_rate", C.c_int), ("harmonic_num", C.c_int)]
 
 
 EXPORTS = [
@@ -64,7 +65,7 @@ EXPORTS = [
     "maa_ctx_set_stream", "maa_ctx_set_precision", "maa_ctx_workspace_bytes", "maa_prof_begin", "maa_prof_end", "maa_unet_create", "maa_unet_destroy",
     "maa_unet_set_context", "maa_unet_forward", "maa_ddim_update", "maa_ddim_sample", "maa_vae_create",
     "maa_vae_destroy", "maa_vae_decode", "maa_vae_encode_moments", "maa_vocoder_create", "maa_vocoder_destroy",
-    "maa_vocoder_forward", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
+    "maa_vocoder_forward", "maa_vocoder_forward_f0", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
     "maa_op_attention", "maa_op_conv_transpose1d", "maa_op_snake_aa", "maa_op_bench_conv",
 ]
 
@@ -107,6 +108,7 @@ def load():
         "maa_vocoder_create": [vp, C.POINTER(maa_vocoder_config), C.POINTER(maa_tensor), ci, C.POINTER(vp)],
         "maa_vocoder_destroy": [vp],
         "maa_vocoder_forward": [vp, vp, vp, ci, ci, vp],
+        "maa_vocoder_forward_f0": [vp, vp, vp, vp, vp, vp, ci, ci, vp],
         "maa_op_linear": [vp, vp, ci, ci, fp, fp, ci, ci, vp],
         "maa_op_conv": [vp, vp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci, ci],
         "maa_op_groupnorm": [vp, vp, ci, ci, ci, fp, fp, cf, ci, vp],

@@ -347,6 +347,10 @@ class Vocoder:
                 c.resblock_dilation_sizes[j][m] = int(d)
         c.snake_beta = int(cfg.get("activation", "") == "snakebeta")
         c.snake_logscale = int(cfg.get("snake_logscale", False))
+        self.nsf = bool(cfg.get("use_pitch_embed", False))
+        c.use_pitch_embed = int(self.nsf)
+        c.sampling_rate = int(cfg.get("sampling_rate", 0))
+        c.harmonic_num = self.harmonics = 8 if self.nsf else 0            # hifigan.py:112
         arr, n, keep = L.tensor_list(state_dict)
         h = C.c_void_p()
         with ctx.lock:
@@ -363,7 +367,33 @@ class Vocoder:
             L.check(self.ctx.lib.maa_vocoder_forward(self.ctx.h, self.h, L.dptr(mel), B, T, L.dptr(wav)))
         return wav
 
-    __call__ = forward
+    def forward_f0(self, mel, f0, rand_ini=None, noise=None):
+        """NSF branch (HifiGanGenerator.forward(x, f0), hifigan.py:144-157): mel [B, num_mels, T], f0 [B, T] in Hz.
+        rand_ini [B, 9] / noise [B, T*hop, 9] are the two tensors SineGen.forward draws (source.py:355-358, 425); when
+        omitted they are drawn here with torch's global generator in the reference's order and on the mel's device."""
+        if not self.nsf:
+            raise L.MaaError("this generator has no NSF branch (use_pitch_embed is off)")
+        dev = self.ctx.device
+        mel, f0 = _f32(mel, dev), _f32(f0, dev)
+        B, _, T = mel.shape
+        if tuple(f0.shape) != (B, T):
+            raise L.MaaError("forward_f0: f0 must be [B=%d, T=%d], got %s" % (B, T, tuple(f0.shape)))
+        H1, Ln = self.harmonics + 1, T * self.hop
+        if rand_ini is None:
+            rand_ini = torch.rand(B, H1, device=dev)
+        if noise is None:
+            noise = torch.randn(B, Ln, H1, device=dev)
+        rand_ini, noise = _f32(rand_ini, dev), _f32(noise, dev)
+        if tuple(rand_ini.shape) != (B, H1) or tuple(noise.shape) != (B, Ln, H1):
+            raise L.MaaError("forward_f0: rand_ini must be [%d, %d] and noise [%d, %d, %d]" % (B, H1, B, Ln, H1))
+        wav = torch.empty(B, 1, Ln, device=dev)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_vocoder_forward_f0(self.ctx.h, self.h, L.dptr(mel), L.dptr(f0), L.dptr(rand_ini),
+                                                        L.dptr(noise), B, T, L.dptr(wav)))
+        return wav
+
+    def __call__(self, mel, f0=None, **kw):
+        return self.forward(mel) if f0 is None else self.forward_f0(mel, f0, **kw)
 
     def close(self):
         if getattr(self, "h", None):

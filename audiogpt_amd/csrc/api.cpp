@@ -286,6 +286,14 @@ int maa_vocoder_forward(maa_ctx* ctx, maa_vocoder* v, const float* d_mel, int B,
         v->m->forward(ctx->c, d_mel, B, T, d_wav);
     });
 }
+int maa_vocoder_forward_f0(maa_ctx* ctx, maa_vocoder* v, const float* d_mel, const float* d_f0, const float* d_rand_ini,
+                           const float* d_noise, int B, int T, float* d_wav) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(v && d_mel && d_f0 && d_rand_ini && d_noise && d_wav && B > 0 && T > 0, "bad vocoder_forward_f0 arguments");
+        v->m->forward_f0(ctx->c, d_mel, d_f0, d_rand_ini, d_noise, B, T, d_wav);
+    });
+}
 
 // ------------------------------------------------------------------------------------------ operators
 // MAA_OP_PRESPLIT=1 (tests): hand the activation to the contraction in the split32 form a normalisation would

@@ -512,12 +512,26 @@ Dma2Plan plan_impl(const IGemm& p) {
             return pl;
         }
     }
-    // default policy (DESIGN.md 3.2 has the sweep it comes from)
-    if (p.K < 1024 || ncols < 128) return pl;
-    pl.cfg = 0;
-    pl.ns = 2;
-    pl.pipe = 0;
-    pl.S = fit_slices(nchunks, (p.K + 720) / 1440);
+    // default policy, from the sweeps of profiles/r2_dma2_sweep*.txt and the in-pipeline A/B of r2_dma2_inpipe.txt:
+    //   * long-K contractions only (K >= 2048: the 3x3 convolutions and ff.net.2 at 5x39); below that the round-1 kernels
+    //     win (ten or twenty chunks do not amortise the wide tile's prologue and the slab round trip);
+    //   * N = 320 (the 10x78 level): one 128x320 tile holds all output channels -- no N padding (128x128 tiles waste 17 %
+    //     there) and the weights are read once per M tile;
+    //   * otherwise 128x128 tiles with the in-wave pipelined loop, four LDS stages;
+    //   * two K slices: twice the workgroups for the 5x39 level's 125 tiles at the price of one slab round trip
+    //     (more slices lose to the reduce traffic, fewer leave half the CUs idle).
+    if (p.K < 2048 || ncols < 128 || p.geglu) return pl;
+    if (ncols == 320) {
+        pl.cfg = 2;
+        pl.ns = 2;
+        pl.pipe = 0;
+    } else {
+        pl.cfg = 0;
+        pl.ns = 4;
+        pl.pipe = 1;
+    }
+    pl.pf = 0;
+    pl.S = fit_slices(nchunks, 2);
     return pl;
 }
 

@@ -210,6 +210,9 @@ void launch_ddim_prepare(const Ctx& ctx, const float* x, const float* concat, in
 // BigVGAN Activation1d on [B, L, C]: up2 FIR -> snake -> down2 FIR (replicate padding)
 void launch_snake_aa(const Ctx& ctx, const float* x, int B, int L, int C, const float* inv_beta, const float* alpha,
                      float* out);
+// NSF harmonic source (nsf.hip): f0 [B, T] -> sines [B, T*hop, harmonics+1] (scratch) -> har [B, T*hop]
+void launch_nsf_source(const Ctx& ctx, const float* f0, int B, int T, int hop, float sampling_rate, const float* rand_ini,
+                       const float* noise, int harmonics, const float* w, const float* bias, float* sines, float* har);
 void launch_leaky(const Ctx& ctx, const float* x, long long n, float slope, float* out);
 void launch_clamp_affine(const Ctx& ctx, const float* x, long long n, float mul, float add, float lo, float hi,
                          float* out);

@@ -45,6 +45,9 @@ public:
     Vocoder(const maa_vocoder_config& cfg, const StateDict& sd, int precision);
     ~Vocoder();
     void forward(Ctx& ctx, const float* mel, int B, int T, float* wav);
+    // NSF branch: f0 [B, T], rand_ini [B, harmonics+1], noise [B, T*hop, harmonics+1] (see maa.h)
+    void forward_f0(Ctx& ctx, const float* mel, const float* f0, const float* rand_ini, const float* noise, int B, int T,
+                    float* wav);
     int hop() const;
 
 private:

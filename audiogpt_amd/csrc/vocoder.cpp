@@ -8,6 +8,8 @@
 //   * `xt + x` and the MRF mean (rb0+rb1+rb2)/3 are igemm epilogues (out_scale 1/3, accumulate)
 //   * ConvTranspose1d runs as two polyphase GEMMs writing interleaved output rows (runtime.cpp)
 //   * weight-norm (weight_g, weight_v) is folded at load exactly as remove_weight_norm does
+//   * NSF branch (hifigan.py:111-132, 145-157): the harmonic source comes from nsf.hip; each stage's strided
+//     noise_convs[i](har_source) is one more implicit GEMM that accumulates into the ups[i] output (x = x + x_source)
 #include "models.h"
 
 #include <cmath>
@@ -80,6 +82,10 @@ struct Vocoder::Impl {
     std::vector<ResBlockW> rbs;
     float *post_alpha = nullptr, *post_inv_beta = nullptr;
     int hop = 1;
+    // NSF branch
+    std::vector<PackedW> noise_convs;
+    std::vector<int> noise_stride;
+    float *src_w = nullptr, *src_b = nullptr;     // m_source.l_linear [1, harmonics+1], [1]
 
     void snake_params(const StateDict& sd, const std::string& p, float** alpha, float** inv_beta) {
         // activations.py:107-119: alpha, beta = exp(param) if logscale; x + 1/(beta + 1e-9) * sin^2(alpha x)
@@ -154,6 +160,22 @@ struct Vocoder::Impl {
         }
         if (big) snake_params(sd, "activation_post.", &post_alpha, &post_inv_beta);
         conv_post = ws.pack_conv(sd, "conv_post.weight", "conv_post.bias", 1, 7);
+        if (cfg.use_pitch_embed) {
+            MAA_CHECK(!big, "the NSF branch belongs to the HiFi-GAN generator");
+            MAA_CHECK(cfg.harmonic_num > 0 && cfg.sampling_rate > 0, "NSF branch needs harmonic_num and sampling_rate");
+            const HostTensor& lw = get(sd, "m_source.l_linear.weight");
+            MAA_CHECK(lw.numel() == cfg.harmonic_num + 1, "m_source.l_linear.weight shape");
+            src_w = ws.vec(sd, "m_source.l_linear.weight");
+            src_b = ws.vec(sd, "m_source.l_linear.bias");
+            for (int i = 0; i < cfg.n_upsamples; ++i) {
+                int s = 1;
+                for (int q = i + 1; q < cfg.n_upsamples; ++q) s *= cfg.upsample_rates[q];
+                const bool last = i + 1 == cfg.n_upsamples;
+                const std::string name = "noise_convs." + std::to_string(i);
+                noise_convs.push_back(ws.pack_conv(sd, name + ".weight", name + ".bias", 1, last ? 1 : 2 * s));
+                noise_stride.push_back(last ? 1 : s);
+            }
+        }
     }
 
     // dilated "same" conv1d on [B, L, C]
@@ -175,7 +197,8 @@ struct Vocoder::Impl {
         conv_into(ctx, x, nullptr, c.w, o, out);
     }
 
-    void forward(Ctx& ctx, const float* mel, int B, int T, float* wav) {
+    // har: harmonic source [B, T*hop] of the NSF branch, or null
+    void forward(Ctx& ctx, const float* mel, int B, int T, float* wav, const float* har = nullptr) {
         const bool big = cfg.kind == 1;
         T4 m = alloc_t(ctx, B, 1, T, cfg.num_mels);
         launch_nchw_to_nhwc(ctx, mel, B, cfg.num_mels, T, m.p);
@@ -224,6 +247,23 @@ struct Vocoder::Impl {
                 launch_igemm(ctx, p);
             }
             L = Lo;
+            if (har) {      // x = x + noise_convs[i](har_source)   (hifigan.py:155-157; Conv1d(1, C, 2s, stride s, pad s/2))
+                T4 hs;
+                hs.B = B;
+                hs.H = 1;
+                hs.W = T * hop;
+                hs.C = 1;
+                hs.p = const_cast<float*>(har);
+                ConvOpt o;
+                o.KH = 1;
+                o.KW = noise_convs[i].K;
+                o.stride = noise_stride[i];
+                o.pad = noise_stride[i] > 1 ? noise_stride[i] / 2 : 0;
+                o.pad_h = 0;
+                o.accumulate = 1;
+                MAA_CHECK((hs.W + 2 * o.pad - o.KW) / o.stride + 1 == L, "noise_convs output length");
+                conv_into(ctx, hs, nullptr, noise_convs[i], o, y);
+            }
             // MRF: x = (rb_0(y) + rb_1(y) + rb_2(y)) / n on the SAME input (hifigan.py:158-164)
             T4 xs = alloc_t(ctx, B, 1, L, u.cout);
             const size_t mk = ctx.ws.mark();
@@ -290,8 +330,26 @@ Vocoder::~Vocoder() { delete impl_; }
 int Vocoder::hop() const { return impl_->hop; }
 
 void Vocoder::forward(Ctx& ctx, const float* mel, int B, int T, float* wav) {
+    MAA_CHECK(!impl_->cfg.use_pitch_embed, "this generator was built with use_pitch_embed: call maa_vocoder_forward_f0");
     PrecisionGuard pg(ctx, impl_->precision);
     run_sized(ctx, [&] { impl_->forward(ctx, mel, B, T, wav); });
+}
+
+void Vocoder::forward_f0(Ctx& ctx, const float* mel, const float* f0, const float* rand_ini, const float* noise, int B,
+                         int T, float* wav) {
+    Impl& m = *impl_;
+    MAA_CHECK(m.cfg.use_pitch_embed, "generator built without use_pitch_embed has no NSF branch");
+    PrecisionGuard pg(ctx, m.precision);
+    run_sized(ctx, [&] {
+        const long long n = (long long)B * T * m.hop;
+        float* har = ctx.ws.alloc_f((size_t)n);
+        const size_t mk = ctx.ws.mark();
+        float* sines = ctx.ws.alloc_f((size_t)n * (m.cfg.harmonic_num + 1));
+        launch_nsf_source(ctx, f0, B, T, m.hop, (float)m.cfg.sampling_rate, rand_ini, noise, m.cfg.harmonic_num, m.src_w,
+                          m.src_b, sines, har);
+        ctx.ws.release(mk);
+        m.forward(ctx, mel, B, T, wav, har);
+    });
 }
 
 }  // namespace maa

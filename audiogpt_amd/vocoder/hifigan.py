@@ -1,7 +1,8 @@
 """HiFi-GAN / BigVGAN vocoder objects with the reference's Python surfaces, backed by the HIP library.
 
   HifiGanGenerator(h)(x[B,80,T], f0=None) -> [B,1,T*hop], .remove_weight_norm(), .load_state_dict(sd)
-        NeuralSeq/modules/hifigan/hifigan.py:104-178 (the NSF branch, use_pitch_embed, is not on this path)
+        NeuralSeq/modules/hifigan/hifigan.py:104-178, including the NSF branch (use_pitch_embed: f0 -> harmonic source ->
+        noise_convs), which runs on the device too (csrc/nsf.hip)
   VocoderHifigan(ckpt_dir, device).vocode(spec)      text_to_audio/Make_An_Audio/vocoder/hifigan/modules.py:296-317
   VocoderBigVGAN(ckpt_dir, device).vocode(spec)      text_to_audio/Make_An_Audio/vocoder/bigvgan/models.py:393-414
   HifiGAN().spec2wav(mel[T,80]) + register_vocoder   NeuralSeq/vocoders/hifigan.py:39-69, vocoders/base_vocoder.py:1-39
@@ -47,6 +48,9 @@ def _cfg_from_h(h, kind="hifigan"):
                sampling_rate=g("sampling_rate", g("audio_sample_rate", 22050)))
     if cfg["resblock"] != "1":
         raise NotImplementedError("only resblock '1' (the shipped configs) is implemented")
+    if g("use_pitch_embed", False):
+        cfg["use_pitch_embed"] = True
+        cfg["sampling_rate"] = g("audio_sample_rate", cfg["sampling_rate"])
     if kind == "bigvgan":
         cfg["activation"] = g("activation", "snakebeta")
         cfg["snake_logscale"] = bool(g("snake_logscale", True))
@@ -58,8 +62,6 @@ class HifiGanGenerator(object):
     weight-norm) or are seeded-random until then."""
 
     def __init__(self, h, c_out=1, device="cuda:0", ctx=None, seed=2, precision=None):
-        if isinstance(h, dict) and h.get("use_pitch_embed"):
-            raise NotImplementedError("NSF branch (use_pitch_embed) is a 'next' row, not on this path")
         self.h = h
         self.cfg = _cfg_from_h(h)
         self.ctx = ctx or Context(device, precision=precision or default_precision())
@@ -93,10 +95,12 @@ class HifiGanGenerator(object):
     def to(self, device):
         return self
 
-    def forward(self, x, f0=None):
-        if f0 is not None:
-            raise NotImplementedError("NSF f0 conditioning is not on this path")
-        return self._build()(x)
+    def forward(self, x, f0=None, rand_ini=None, noise=None):
+        """hifigan.py:144-169.  f0 [B, T] engages the NSF branch (the generator must have been built with
+        use_pitch_embed); rand_ini / noise optionally pin SineGen's two random draws."""
+        if f0 is None:
+            return self._build()(x)
+        return self._build().forward_f0(x, f0, rand_ini=rand_ini, noise=noise)
 
     __call__ = forward
 
@@ -171,15 +175,20 @@ class HifiGAN(BaseVocoder):
     def __init__(self, hparams=None, device="cuda:0", ctx=None, state_dict=None, precision=None):
         h = dict(hparams or C.HIFIGAN_NS_512)
         h.setdefault("use_pitch_embed", False)
+        self.use_nsf = bool(h.get("use_nsf", h["use_pitch_embed"]))      # hparams['use_nsf'] of the singing configs
         self.model = HifiGanGenerator(h, device=device, ctx=ctx, precision=precision)
         if state_dict is not None:
             self.model.load_state_dict(state_dict, strict=True)
         self.device = self.model.device
 
     def spec2wav(self, mel, **kwargs):
-        if kwargs.get("f0") is not None:
-            raise NotImplementedError("NSF f0 conditioning is not on this path")
+        """vocoders/hifigan.py:55-69: f0 given and hparams['use_nsf'] -> self.model(c, f0), else self.model(c)."""
         with torch.no_grad():
             c = torch.as_tensor(mel, dtype=torch.float32).unsqueeze(0).transpose(2, 1)
-            y = self.model(c).view(-1)
+            f0 = kwargs.get("f0")
+            if f0 is not None and self.use_nsf:
+                f0 = torch.as_tensor(np.asarray(f0), dtype=torch.float32)[None, :]
+                y = self.model(c, f0).view(-1)
+            else:
+                y = self.model(c).view(-1)
         return y.cpu().numpy()

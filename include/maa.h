@@ -168,6 +168,9 @@ typedef struct maa_vocoder_config {
     int n_kernels, resblock_kernel_sizes[8];
     int n_dilations, resblock_dilation_sizes[8][8];
     int snake_beta, snake_logscale; /* BigVGAN: activation == "snakebeta", snake_logscale */
+    /* NSF branch (h['use_pitch_embed'], NeuralSeq/modules/hifigan/hifigan.py:111-115,124-132): harmonic-plus-noise source
+     * of `harmonic_num` overtones at `sampling_rate` (h['audio_sample_rate']), added through noise_convs after each ups[i] */
+    int use_pitch_embed, sampling_rate, harmonic_num;
 } maa_vocoder_config;
 /* tensors: generator state_dict (weight_g/weight_v pairs or folded `weight`), keys as
  * NeuralSeq/modules/hifigan/hifigan.py:104-142 / vocoder/bigvgan/models.py:133-179 */
@@ -178,6 +181,13 @@ int maa_vocoder_destroy(maa_vocoder* v);
  * (vocoder/hifigan/modules.py:111-127), BigVGAN.forward (bigvgan/models.py:181-203):
  * d_mel [B, num_mels, T] -> d_wav [B, T*hop] */
 int maa_vocoder_forward(maa_ctx* ctx, maa_vocoder* v, const float* d_mel, int B, int T, float* d_wav);
+/* replaces: HifiGanGenerator.forward(x, f0) with use_pitch_embed (hifigan.py:144-169: f0_upsamp, m_source, noise_convs)
+ * and SineGen / SourceModuleHnNSF (NeuralSeq/modules/parallel_wavegan/models/source.py:399-436, 526-535).
+ * d_f0 [B, T] in Hz (0 = unvoiced).  The two random tensors SineGen.forward draws are inputs:
+ * d_rand_ini [B, harmonic_num + 1] ~ U[0,1) (initial phase of the overtones; column 0 is ignored) and
+ * d_noise [B, T*hop, harmonic_num + 1] ~ N(0,1) (additive noise). */
+int maa_vocoder_forward_f0(maa_ctx* ctx, maa_vocoder* v, const float* d_mel, const float* d_f0,
+                           const float* d_rand_ini, const float* d_noise, int B, int T, float* d_wav);
 
 /* ---- single-operator entry points (parity tests and profiling of individual kernels) ------------ */
 /* y[M,N] = A[M,K] * W^T (+bias) with W given as torch Linear weight [N,K] on the HOST; A, y on device */
