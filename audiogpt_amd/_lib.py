@@ -60,12 +60,23 @@ class maa_vocoder_config(C.Structure):
                 ("use_pitch_embed", C.c_int), ("sampling_rate", C.c_int), ("harmonic_num", C.c_int)]
 
 
+class maa_diffnet_config(C.Structure):
+    _fields_ = [("in_dims", C.c_int), ("hidden_size", C.c_int), ("residual_layers", C.c_int),
+                ("residual_channels", C.c_int), ("dilation_cycle_length", C.c_int)]
+
+
+class maa_plms_args(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("K_step", C.c_int), ("interval", C.c_int), ("timesteps", C.c_int),
+                ("d_cond", C.c_void_p), ("h_alphas_cumprod", C.POINTER(C.c_float)), ("use_graph", C.c_int)]
+
+
 EXPORTS = [
     "maa_last_error", "maa_version", "maa_ctx_create", "maa_ctx_destroy", "maa_ctx_synchronize",
     "maa_ctx_set_stream", "maa_ctx_set_precision", "maa_ctx_workspace_bytes", "maa_prof_begin", "maa_prof_end", "maa_unet_create", "maa_unet_destroy",
     "maa_unet_set_context", "maa_unet_forward", "maa_ddim_update", "maa_ddim_sample", "maa_vae_create",
     "maa_vae_destroy", "maa_vae_decode", "maa_vae_encode_moments", "maa_vocoder_create", "maa_vocoder_destroy",
-    "maa_vocoder_forward", "maa_vocoder_forward_f0", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
+    "maa_vocoder_forward", "maa_vocoder_forward_f0", "maa_diffnet_create", "maa_diffnet_destroy", "maa_diffnet_forward",
+    "maa_plms_sample", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
     "maa_op_attention", "maa_op_conv_transpose1d", "maa_op_snake_aa", "maa_op_bench_conv",
 ]
 
@@ -109,6 +120,10 @@ def load():
         "maa_vocoder_destroy": [vp],
         "maa_vocoder_forward": [vp, vp, vp, ci, ci, vp],
         "maa_vocoder_forward_f0": [vp, vp, vp, vp, vp, vp, ci, ci, vp],
+        "maa_diffnet_create": [vp, C.POINTER(maa_diffnet_config), C.POINTER(maa_tensor), ci, C.POINTER(vp)],
+        "maa_diffnet_destroy": [vp],
+        "maa_diffnet_forward": [vp, vp, vp, vp, vp, ci, ci, vp],
+        "maa_plms_sample": [vp, vp, C.POINTER(maa_plms_args), vp],
         "maa_op_linear": [vp, vp, ci, ci, fp, fp, ci, ci, vp],
         "maa_op_conv": [vp, vp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci, ci],
         "maa_op_groupnorm": [vp, vp, ci, ci, ci, fp, fp, cf, ci, vp],

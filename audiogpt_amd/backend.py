@@ -405,3 +405,65 @@ class Vocoder:
             self.close()
         except Exception:
             pass
+
+
+class DiffNet:
+    """maa_diffnet handle: DiffSinger's denoiser (NeuralSeq/modules/diff/net.py:84-130) and the PLMS loop over it
+    (NeuralSeq/modules/diff/shallow_diffusion_tts.py:166-201, 262-269)."""
+
+    def __init__(self, ctx, cfg, state_dict):
+        self.ctx, self.cfg = ctx, cfg
+        c = L.maa_diffnet_config()
+        c.in_dims, c.hidden_size = cfg["in_dims"], cfg["hidden_size"]
+        c.residual_layers, c.residual_channels = cfg["residual_layers"], cfg["residual_channels"]
+        c.dilation_cycle_length = cfg["dilation_cycle_length"]
+        arr, n, keep = L.tensor_list(state_dict)
+        h = C.c_void_p()
+        with ctx.lock:
+            L.check(ctx.lib.maa_diffnet_create(ctx.h, C.byref(c), arr, n, C.byref(h)))
+        self.h = h
+
+    def forward(self, spec, diffusion_step, cond):
+        """spec [B, 1, M, T], diffusion_step [B] or [B, 1] (integer steps), cond [B, H, T] -> eps [B, 1, M, T]."""
+        dev = self.ctx.device
+        spec, cond = _f32(spec, dev), _f32(cond, dev)
+        t = _f32(torch.as_tensor(diffusion_step).reshape(-1), dev)
+        B, _, M, T = spec.shape
+        if M != self.cfg["in_dims"] or tuple(cond.shape) != (B, self.cfg["hidden_size"], T) or t.shape[0] != B:
+            raise L.MaaError("DiffNet.forward: spec %s / step %s / cond %s do not fit in_dims %d, hidden_size %d"
+                             % (tuple(spec.shape), tuple(t.shape), tuple(cond.shape), self.cfg["in_dims"], self.cfg["hidden_size"]))
+        out = torch.empty_like(spec)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_diffnet_forward(self.ctx.h, self.h, L.dptr(spec), L.dptr(t), L.dptr(cond), B, T, L.dptr(out)))
+        return out
+
+    __call__ = forward
+
+    def plms_sample(self, x, cond, alphas_cumprod, K_step, interval, use_graph=True):
+        """x [B, 1, M, T] = x_K -> x_0 after the pndm_speedup loop: t = K_step - interval, ..., 0."""
+        dev = self.ctx.device
+        x = _f32(x, dev).clone()
+        cond = _f32(cond, dev)
+        B, _, M, T = x.shape
+        if M != self.cfg["in_dims"] or tuple(cond.shape) != (B, self.cfg["hidden_size"], T):
+            raise L.MaaError("plms_sample: x %s / cond %s do not fit the denoiser" % (tuple(x.shape), tuple(cond.shape)))
+        ac = np.ascontiguousarray(np.asarray(alphas_cumprod), dtype=np.float32)
+        a = L.maa_plms_args()
+        a.B, a.T, a.K_step, a.interval, a.timesteps = B, T, int(K_step), int(interval), int(ac.shape[0])
+        a.d_cond = cond.data_ptr()
+        a.h_alphas_cumprod = ac.ctypes.data_as(C.POINTER(C.c_float))
+        a.use_graph = int(use_graph)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_plms_sample(self.ctx.h, self.h, C.byref(a), L.dptr(x)))
+        return x
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.maa_diffnet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -22,6 +22,9 @@ struct maa_vae {
 struct maa_vocoder {
     std::unique_ptr<maa::Vocoder> m;
 };
+struct maa_diffnet {
+    std::unique_ptr<maa::DiffNet> m;
+};
 
 namespace {
 
@@ -296,6 +299,39 @@ int maa_vocoder_forward_f0(maa_ctx* ctx, maa_vocoder* v, const float* d_mel, con
 }
 
 // ------------------------------------------------------------------------------------------ operators
+// ------------------------------------------------------------------------------------------ DiffSinger
+int maa_diffnet_create(maa_ctx* ctx, const maa_diffnet_config* cfg, const maa_tensor* tensors, int n_tensors,
+                       maa_diffnet** out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(cfg && out && cfg->in_dims > 0 && cfg->hidden_size > 0 && cfg->residual_layers > 0 &&
+                      cfg->residual_channels > 0 && cfg->residual_channels % 2 == 0 && cfg->dilation_cycle_length > 0,
+                  "bad DiffNet config");
+        auto sd = to_state_dict(tensors, n_tensors);
+        auto* d = new maa_diffnet;
+        d->m.reset(new maa::DiffNet(*cfg, sd, ctx->c.dtype));
+        *out = d;
+    });
+}
+int maa_diffnet_destroy(maa_diffnet* d) {
+    return guarded([&] { delete d; });
+}
+int maa_diffnet_forward(maa_ctx* ctx, maa_diffnet* d, const float* d_spec, const float* d_t, const float* d_cond, int B,
+                        int T, float* d_eps) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d && d_spec && d_t && d_cond && d_eps && B > 0 && T > 0, "bad diffnet_forward arguments");
+        d->m->forward(ctx->c, d_spec, d_t, d_cond, B, T, d_eps);
+    });
+}
+int maa_plms_sample(maa_ctx* ctx, maa_diffnet* d, const maa_plms_args* args, float* d_x) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d && args && d_x, "bad plms_sample arguments");
+        d->m->plms_sample(ctx->c, *args, d_x);
+    });
+}
+
 // MAA_OP_PRESPLIT=1 (tests): hand the activation to the contraction in the split32 form a normalisation would
 // have written, so the op entry points exercise the LDS-DMA engines too.
 static bool op_presplit(const maa::Ctx& c, int channels, bool other_prologue) {

@@ -95,6 +95,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI]
                         if (p.rowadd) v += p.rowadd[(long long)(m / rpb) * p.ld_rowadd + n];
                         if (resp) v += resp[(long long)m * p.ldr + n];
                         if (p.act == 1) v = tanhf(v);
+                        else if (p.act == 2) v = fmaxf(v, 0.f);
                         v *= p.out_scale;
                         if (p.c_split) {
                             store_split1(cp + (long long)m * p.ldc, n, v);

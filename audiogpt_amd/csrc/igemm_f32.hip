@@ -324,6 +324,7 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
                         if (p.rowadd) v += p.rowadd[(long long)(m / rpb) * p.ld_rowadd + n];
                         if (resp) v += resp[(long long)m * p.ldr + n];
                         if (p.act == 1) v = tanhf(v);
+                        else if (p.act == 2) v = fmaxf(v, 0.f);
                         v *= p.out_scale;
                         float* dst = cp + (long long)m * p.ldc + n;
                         if (p.accumulate) v += *dst;

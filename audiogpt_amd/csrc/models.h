@@ -55,6 +55,19 @@ private:
     Impl* impl_;
 };
 
+class DiffNet {
+public:
+    DiffNet(const maa_diffnet_config& cfg, const StateDict& sd, int precision);
+    ~DiffNet();
+    void forward(Ctx& ctx, const float* spec, const float* t, const float* cond, int B, int T, float* out);
+    void plms_sample(Ctx& ctx, const maa_plms_args& a, float* d_x);
+    const maa_diffnet_config& config() const;
+
+private:
+    struct Impl;
+    Impl* impl_;
+};
+
 void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x);
 
 }  // namespace maa

@@ -189,6 +189,34 @@ int maa_vocoder_forward(maa_ctx* ctx, maa_vocoder* v, const float* d_mel, int B,
 int maa_vocoder_forward_f0(maa_ctx* ctx, maa_vocoder* v, const float* d_mel, const float* d_f0,
                            const float* d_rand_ini, const float* d_noise, int B, int T, float* d_wav);
 
+/* ---- DiffSinger denoiser + PLMS loop (the singing-voice tool's diffusion hot loop) ---------------
+ * DiffNet: NeuralSeq/modules/diff/net.py:84-130 (hparams hidden_size / residual_layers / residual_channels /
+ * dilation_cycle_length, in_dims = audio_num_mel_bins) */
+typedef struct maa_diffnet_config {
+    int in_dims, hidden_size, residual_layers, residual_channels, dilation_cycle_length;
+} maa_diffnet_config;
+typedef struct maa_diffnet maa_diffnet;
+/* tensors: the `denoise_fn.`-relative state_dict of GaussianDiffusion (input_projection.*, mlp.{0,2}.*,
+ * residual_layers.{i}.{dilated_conv,diffusion_projection,conditioner_projection,output_projection}.*, skip_projection.*,
+ * output_projection.*) */
+int maa_diffnet_create(maa_ctx* ctx, const maa_diffnet_config* cfg, const maa_tensor* tensors, int n_tensors,
+                       maa_diffnet** out);
+int maa_diffnet_destroy(maa_diffnet* d);
+/* replaces: DiffNet.forward(spec, diffusion_step, cond) (net.py:107-130):
+ * d_spec [B, 1, in_dims, T], d_t [B] (the integer diffusion step as float), d_cond [B, hidden_size, T] -> d_eps [B, 1, in_dims, T] */
+int maa_diffnet_forward(maa_ctx* ctx, maa_diffnet* d, const float* d_spec, const float* d_t, const float* d_cond, int B,
+                        int T, float* d_eps);
+/* replaces: the pndm_speedup branch of GaussianDiffusion.forward(infer=True) (shallow_diffusion_tts.py:262-269) with
+ * p_sample_plms (:166-201): t = K_step - interval, ..., 0; d_x [B, 1, in_dims, T] holds x_K on entry and x_0 on return.
+ * h_alphas_cumprod [timesteps]: the fp32 buffer of the reference (:82-96). */
+typedef struct maa_plms_args {
+    int B, T, K_step, interval, timesteps;
+    const float* d_cond;              /* [B, hidden_size, T] */
+    const float* h_alphas_cumprod;    /* host, [timesteps] */
+    int use_graph;
+} maa_plms_args;
+int maa_plms_sample(maa_ctx* ctx, maa_diffnet* d, const maa_plms_args* args, float* d_x);
+
 /* ---- single-operator entry points (parity tests and profiling of individual kernels) ------------ */
 /* y[M,N] = A[M,K] * W^T (+bias) with W given as torch Linear weight [N,K] on the HOST; A, y on device */
 int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w, const float* h_bias, int N,
