@@ -135,7 +135,12 @@ class Inpaint:
                                      precision=precision)
         self.sampler = DDIMSampler(model)
         self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=model.ctx)
-        self.mel_transform = mel_transform      # TRANSFORMS_16000 (extract_mel_spectrogram.py:140-150), pluggable
+        # gen_mel_audio + TRANSFORMS_16000 (audio-chatgpt.py:468-491, extract_mel_spectrogram.py:140-150): the host-side
+        # restatement in audiogpt_amd/mel.py unless the caller plugs in the librosa-backed original
+        if mel_transform is None:
+            from .mel import gen_mel_audio
+            mel_transform = lambda sr, wav: gen_mel_audio((sr, wav))      # noqa: E731
+        self.mel_transform = mel_transform
 
     def make_batch_sd(self, mel, mask, num_samples=1):
         mel = torch.from_numpy(mel)[None, None, ...].to(dtype=torch.float32)
@@ -177,9 +182,6 @@ class Inpaint:
             return self.inpaint(batch=batch, seed=seed, ddim_steps=ddim_steps, num_samples=1, H=mel_bins, W=mel_len)
 
     def inference(self, input_audio, mel_and_mask, seed=55, ddim_steps=100):
-        if self.mel_transform is None:
-            raise RuntimeError("Inpaint.inference needs the 16 kHz log-mel front end (TRANSFORMS_16000, librosa) "
-                               "passed as mel_transform=; it is outside the accelerated path (SURVEY.md 8f N4)")
         from PIL import Image
         torch.set_grad_enabled(False)
         show_mel = np.array(Image.open(mel_and_mask["image"]).convert("L")) / 255

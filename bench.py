@@ -18,6 +18,10 @@ Secondary workloads (reported under "secondary" in the same JSON line at N = 1, 
                (clip(N(-2.25, 1.5), -6, 1.5), seed 7) -> wave [64, 262144] = 760.9 audio-seconds per step, mel resident
                in HBM; roofline of its dominant kernel and of the whole pass against the 40.24 TFLOP it computes.
 
+  mixed     -- BASELINE configs[4] on one GPU: 8 inpaint clips (VAE encode, concat-conditioned DDIM [8,9,10,106] without
+               CFG, decode, compositing, BigVGAN 848 frames) + 8 image-to-audio clips (1-token context, CFG 3, BigVGAN 624
+               frames), 100 DDIM steps each, every step a hipGraph replay = 188.4 audio-seconds per step.
+
 Output: ONE JSON line on rank 0 with metric/value plus
   roofline     -- the dominant kernel (the implicit-GEMM engine): algorithmic FLOPs (2*M*N*K) of its launches / their
                   summed hipEvent durations, against the dense MFMA peak of the precision mode (157.3 TFLOP/s fp32,
@@ -193,6 +197,81 @@ def run_hifigan64(dev, precision, steps, warmup, cpu_base=True, roofline=True):
     return res
 
 
+def run_mixed(dev, precision, steps, warmup, n=PROMPTS_PER_GPU, S=DDIM_STEPS, roofline=True):
+    """BASELINE configs[4] on one GPU: a mixed tool batch, each tool's DDIM step captured as a hipGraph.
+      inpaint: n masked mels [80, 848] (U(0,1), random rectangle masks) -> VAE encode + posterior sample -> concat-conditioned
+               DDIM over [n, 9, 10, 106] without CFG (inpaint beta schedule) -> decode -> composite with the input mel ->
+               BigVGAN (848 frames, 13.568 s each)                                       (audio-chatgpt.py:500-528)
+      i2a:     n image embeddings (L2-normalised N(0,1) [n, 1, 1024]) -> DDIM with CFG 3 over a 1-token context (UNet batch
+               2n, context also added to the time embedding) -> decode -> BigVGAN (624 frames, 9.984 s each)   (:232-261)
+    A step = both tools once; value = audio-seconds of both per wall second."""
+    from audiogpt_amd.pipeline import MakeAnAudio
+    inp = MakeAnAudio(dev, ldm=C.LDM_INPAINT, vocoder_cfg=C.BIGVGAN_16K, seeds=(5, 1, 3), with_encoder=True, precision=precision)
+    i2a = MakeAnAudio(dev, ldm=C.LDM_I2A, vocoder_cfg=C.BIGVGAN_16K, seeds=(4, 1, 3), precision=precision)
+    g = torch.Generator().manual_seed(77)
+    mel = torch.rand(n, 1, 80, 848, generator=g)
+    mask = torch.zeros(n, 1, 80, 848)
+    for b in range(n):
+        t0, f0 = 100 + 40 * b, 8 + 3 * b
+        mask[b, :, f0:f0 + 40, t0:t0 + 300] = 1.0
+    mel, mask = mel.to(dev), mask.to(dev)
+    emb = torch.randn(n, 1, 1024, generator=g)
+    emb = (emb / emb.norm(dim=-1, keepdim=True)).to(dev)
+    uc = torch.nn.functional.layer_norm(torch.randn(1, 1, 1024, generator=g), (1024,)).expand(n, -1, -1).contiguous().to(dev)
+    noise = torch.randn(n, 4, 10, 106, generator=g).to(dev)
+    xT_inp = torch.randn(n, 4, 10, 106, generator=g).to(dev)
+    xT_i2a = torch.from_numpy(np.random.RandomState(55).randn(n, *LATENT)).float().to(dev)
+
+    def one_step():
+        # inpaint (tools.Inpaint.inpaint, batched)
+        mom = inp.vae.encode_moments((1 - mask) * mel * 2 - 1)
+        mean, logvar = mom.chunk(2, dim=1)
+        zc = mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise
+        cc = torch.nn.functional.interpolate(mask * 2 - 1, size=zc.shape[-2:])
+        z = inp.sample_latents(xT_inp, S=S, concat=torch.cat((zc, cc), dim=1))
+        pred = inp.decode(z)[:, None]
+        comp = (1 - mask) * mel + mask * pred
+        w1 = inp.vocode(comp[:, 0])
+        # image -> audio
+        w2, _, _ = i2a.generate(xT_i2a, emb, uc, 3.0, S)
+        return w1, w2
+
+    for _ in range(warmup):
+        one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w1, w2 = one_step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    audio_s = (w1.shape[0] * w1.shape[1] + w2.shape[0] * w2.shape[1]) / 16000.0
+    res = {"metric": "generated audio-seconds/sec (mixed tool batch: inpaint 13.6 s clips + image-to-audio 10 s clips, 100 DDIM steps)",
+           "value": audio_s * steps / elapsed, "unit": "audio-seconds/sec", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True, "dtype": precision,
+           "data": "synthetic mels U(0,1) with rectangle masks, L2-normalised N(0,1) image embeddings; seeded random-init weights",
+           "config": {"workload": "inpaint x%d ([%d,9,10,106], no CFG) + image-to-audio x%d (CFG 3, 1-token context), %d DDIM steps each, "
+                                  "VAE + BigVGAN, hipGraph-captured steps" % (n, n, n, S), "audio_seconds_per_step": audio_s}}
+    if roofline:
+        inp.ctx.prof_begin()
+        i2a.ctx.prof_begin()
+        mom = inp.vae.encode_moments((1 - mask) * mel * 2 - 1)
+        zc = mom.chunk(2, dim=1)[0]
+        z = inp.sample_latents(xT_inp, S=S, concat=torch.cat((zc, torch.nn.functional.interpolate(mask * 2 - 1, size=zc.shape[-2:])), dim=1), use_graph=False)
+        inp.vocode(inp.decode(z))
+        i2a.generate(xT_i2a, emb, uc, 3.0, S, use_graph=False)
+        rows = inp.ctx.prof_end()
+        for k, v in i2a.ctx.prof_end().items():
+            if k in rows:
+                for f in ("launches", "ms", "flops", "bytes"):
+                    rows[k][f] += v[f]
+            else:
+                rows[k] = v
+        res["roofline"] = roofline_of(rows, precision)
+    inp.close()
+    i2a.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,8 +285,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel table of one profiled batch to stderr")
-    ap.add_argument("--workload", default="t2a", choices=["t2a", "hifigan64"],
-                    help="t2a: BASELINE configs[1] (the headline line, with the others under 'secondary'); hifigan64: configs[2] alone")
+    ap.add_argument("--workload", default="t2a", choices=["t2a", "hifigan64", "mixed"],
+                    help="t2a: BASELINE configs[1] (the headline line, with the others under 'secondary'); hifigan64: configs[2] "
+                         "alone; mixed: configs[4] on one GPU (inpaint + image-to-audio)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the default run")
     args = ap.parse_args()
 
@@ -222,6 +302,11 @@ def main():
         assert world == 1, "the vocoder-only workload is a single-GPU configuration"
         print(json.dumps(run_hifigan64(dev, args.precision, args.steps, args.warmup, not args.no_cpu_baseline,
                                        not args.no_roofline)), flush=True)
+        return
+    if args.workload == "mixed":
+        assert world == 1, "run one mixed batch per GPU (replicas) -- no collective in this workload"
+        print(json.dumps(run_mixed(dev, args.precision, args.steps, args.warmup, args.prompts_per_gpu, args.ddim_steps,
+                                   not args.no_roofline)), flush=True)
         return
     dist = None
     if world > 1:
@@ -311,10 +396,13 @@ def main():
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0 and world == 1 and not args.no_secondary:
         pipe.close()
-        try:
-            result["secondary"] = {"hifigan64": run_hifigan64(dev, args.precision, 3, 1, not args.no_cpu_baseline, not args.no_roofline)}
-        except Exception as e:      # never lose the headline line to a secondary workload
-            result["secondary"] = {"hifigan64": {"error": str(e)[:300]}}
+        result["secondary"] = {}
+        for name, fn in (("hifigan64", lambda: run_hifigan64(dev, args.precision, 3, 1, not args.no_cpu_baseline, not args.no_roofline)),
+                         ("mixed", lambda: run_mixed(dev, args.precision, 2, 1, roofline=not args.no_roofline))):
+            try:
+                result["secondary"][name] = fn()
+            except Exception as e:      # never lose the headline line to a secondary workload
+                result["secondary"][name] = {"error": str(e)[:300]}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist is not None:

@@ -183,6 +183,33 @@ def test_Inpaint_inference_mel_matches_oracle_chain():
     assert np.allclose(inpainted[:, 600:], mel_in[:, 600:848], atol=1e-6)       # outside the mask: the input mel
 
 
+def test_Inpaint_inference_files_in_files_out(tmp_path, monkeypatch):
+    """`Tool(func=Inpaint.inference)` as the Gradio front end calls it (audio-chatgpt.py:529-558): (sr, int16 wave) and
+    the paths of the mel / mask images in, (image file, audio file) out, with the built-in log-mel front end."""
+    from PIL import Image
+    from scipy.io import wavfile
+
+    from audiogpt_amd.tools import Inpaint
+    monkeypatch.chdir(tmp_path)
+    inp = Inpaint("cuda:0")
+    sr = 16000
+    t = np.arange(12 * sr) / sr
+    wav = (0.3 * np.sin(2 * np.pi * (200 + 40 * t) * t) * 32767).astype(np.int16)
+    mel = inp.mel_transform(sr, wav)
+    assert mel.shape[0] == 80 and mel.shape[1] >= 848
+    Image.fromarray((mel[:, :500] * 255).astype(np.uint8)).save(str(tmp_path / "mel.png"))
+    mask = np.zeros((80, 500), dtype=np.uint8)
+    mask[20:60, 100:300] = 255
+    Image.fromarray(mask).save(str(tmp_path / "mask.png"))
+    img_name, wav_name = inp.inference((sr, wav), {"image": str(tmp_path / "mel.png"), "mask": str(tmp_path / "mask.png")},
+                                       ddim_steps=2)
+    assert img_name.startswith("image/") and wav_name.startswith("audio/")
+    out = np.array(Image.open(str(tmp_path / img_name)))
+    assert out.shape[:2] == (80, 500)
+    sr2, data = wavfile.read(str(tmp_path / wav_name))
+    assert sr2 == 16000 and data.dtype == np.int16 and data.shape == (12 * sr,)
+
+
 # ------------------------------------------------------------------------------------------------ vocoder wrappers
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_vocoder_wrappers_match_reference(golden, precision):

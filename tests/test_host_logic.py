@@ -155,3 +155,42 @@ def test_bench_line_contract_of_the_committed_run():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     assert abs(d["value"] - d["config"]["audio_seconds_per_step"] / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
+
+
+def test_mel_front_end_restatement():
+    """audiogpt_amd/mel.py restates librosa's stft / mel filter bank (absent here: parity unpinned, see its docstring).
+    Checked against an independent framing (scipy.signal.stft on the explicitly padded signal), the filter bank's
+    defining properties, an analytic tone, and the TRANSFORMS_16000 level mapping."""
+    import numpy as np
+    import scipy.signal as ss
+
+    from audiogpt_amd import mel as M
+    fb = M.mel_filterbank()
+    assert fb.shape == (80, 513) and fb.dtype == np.float32 and (fb >= 0).all()
+    freqs = np.linspace(0, 8000, 513)
+    centres = (fb * freqs[None]).sum(1) / fb.sum(1)
+    assert (np.diff(centres) > 0).all() and 125 < centres[0] < 200 and 7000 < centres[-1] < 7600
+    assert fb[:, freqs < 125].sum() == 0 and fb[:, freqs > 7600].sum() == 0
+    # Slaney normalisation: every filter integrates to ~1 over frequency (bin width 15.625 Hz)
+    area = fb.sum(1) * (8000 / 512)
+    assert np.allclose(area, 1.0, atol=0.15), (area.min(), area.max())
+    rs = np.random.RandomState(0)
+    x = rs.randn(4 * 16000).astype(np.float32) * 0.1
+    for mode in ("constant", "reflect"):
+        S = M.stft_magnitude(x, pad_mode=mode)
+        assert S.shape == (513, 1 + len(x) // 256)
+        xp = np.pad(x, 512, mode=mode)
+        _, _, Z = ss.stft(xp, window="hann", nperseg=1024, noverlap=768, boundary=None, padded=False)
+        ref = np.abs(Z) * ss.get_window("hann", 1024).sum()
+        assert np.abs(ref - S).max() <= 1e-5 * S.max()
+    t = np.arange(848 * 256) / 16000.0
+    tone = (0.5 * np.sin(2 * np.pi * 1000.0 * t)).astype(np.float32)
+    m = M.transforms_16000(tone)
+    assert m.shape == (80, 849) and m.min() >= 0 and m.max() <= 1
+    k = int(m[:, 400].argmax())
+    assert abs(centres[k] - 1000.0) < 60
+    assert M.transforms_16000(np.zeros(20000, dtype=np.float32)).max() == 0.0        # silence: 20 log10(1e-5) + 80 < 0 -> 0
+    sr, wav = 16000, (tone[:5 * 16000] * 32767).astype(np.int16)
+    assert M.gen_mel_audio((sr, wav)).shape == (80, 1 + (5 * 16000 + 848 * 256) // 256)   # short input: reference's full-clip pad
+    assert M.gen_mel_audio((sr, np.stack([wav, wav], 1))).shape[0] == 80                 # stereo -> mono
+    assert M.gen_mel_audio((32000, np.repeat(wav, 2))).shape[0] == 80                    # resampled to 16 kHz
