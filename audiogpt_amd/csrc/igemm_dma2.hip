@@ -488,7 +488,8 @@ int fit_slices(int nchunks, int S) {
 }
 
 // Which problems take this engine, with which tile and how many K slices: a function of the layer (K, packed N) only.
-// MAA_DMA2 = "off" | "cfg,ns,pipe,S[,kmin[,pf]]" overrides the policy (tuning and tests; read on every launch).
+// MAA_DMA2 = "off" | "cfg,ns,pipe,S[,kmin[,pf[,kmax]]]" overrides the policy for kmin <= K <= kmax (tuning and tests; read
+// on every launch).
 Dma2Plan plan_impl(const IGemm& p) {
     Dma2Plan pl;
     const int ncols = p.N * (p.geglu ? 2 : 1);
@@ -500,16 +501,19 @@ Dma2Plan plan_impl(const IGemm& p) {
     if (!env || !*env) env = std::getenv("MAA_DMA2");
     if (env && *env) {
         if (!std::strcmp(env, "off")) return pl;
-        int cfg = 0, ns = 2, pipe = 0, S = 1, kmin = 0, pf = 0;
-        const int k = std::sscanf(env, "%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &pf);
+        int cfg = 0, ns = 2, pipe = 0, S = 1, kmin = 0, pf = 0, kmax = 1 << 30;
+        const int k = std::sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &pf, &kmax);
         if (k >= 4) {
-            if (p.K < kmin || (p.geglu && cfg == 2)) return pl;
-            pl.cfg = cfg;
-            pl.ns = ns;
-            pl.pipe = pipe;
-            pl.pf = pf;
-            pl.S = fit_slices(nchunks, S);
-            return pl;
+            if (p.K < kmin || (p.geglu && cfg >= 2)) return pl;
+            if (p.K > kmax) env = nullptr;          // outside the override's K range: default policy below
+            if (env) {
+                pl.cfg = cfg;
+                pl.ns = ns;
+                pl.pipe = pipe;
+                pl.pf = pf;
+                pl.S = fit_slices(nchunks, S);
+                return pl;
+            }
         }
     }
     // default policy, from the sweeps of profiles/r2_dma2_sweep*.txt and the in-pipeline A/B of r2_dma2_inpipe.txt:
@@ -542,16 +546,17 @@ Dma2Plan igemm_dma2_plan(const IGemm& p) { return plan_impl(p); }
 size_t igemm_dma2_workspace_floats(const IGemm& p, const Dma2Plan& pl) {
     if (pl.cfg < 0 || pl.S <= 1) return 0;
     const int ncols = p.N * (p.geglu ? 2 : 1);
-    const int BM = pl.cfg == 1 ? 256 : 128, BN = pl.cfg == 2 ? 320 : 128;
+    const int BM = pl.cfg == 1 ? 256 : pl.cfg == 3 ? 64 : 128, BN = pl.cfg >= 2 ? 320 : 128;
     const long long tiles = (long long)((p.M + BM - 1) / BM) * ((ncols + BN - 1) / BN);
     return (size_t)(tiles * pl.S * BM * BN);
 }
 
 const char* igemm_dma2_name(const Dma2Plan& pl) {
-    static const char* names[3][2] = {{"igemm_dma2_bf16x3<128x128>", "igemm_dma2_bf16x3<128x128,splitK>"},
+    static const char* names[4][2] = {{"igemm_dma2_bf16x3<128x128>", "igemm_dma2_bf16x3<128x128,splitK>"},
                                       {"igemm_dma2_bf16x3<256x128>", "igemm_dma2_bf16x3<256x128,splitK>"},
-                                      {"igemm_dma2_bf16x3<128x320>", "igemm_dma2_bf16x3<128x320,splitK>"}};
-    return names[pl.cfg < 0 || pl.cfg > 2 ? 0 : pl.cfg][pl.S > 1];
+                                      {"igemm_dma2_bf16x3<128x320>", "igemm_dma2_bf16x3<128x320,splitK>"},
+                                      {"igemm_dma2_bf16x3<64x320>", "igemm_dma2_bf16x3<64x320,splitK>"}};
+    return names[pl.cfg < 0 || pl.cfg > 3 ? 0 : pl.cfg][pl.S > 1];
 }
 
 // The caller has checked the split32 conditions (both operands split, single source, C % 32 == 0, K % 32 == 0, 16-byte
@@ -581,6 +586,9 @@ void launch_igemm_dma2(const Ctx& ctx, const IGemm& p, int Nb, const Dma2Plan& p
         // 128x320 tiles (all of N = 320 in one tile), 8 waves of 32x160
         case 2200: launch_one<128, 320, 4, 2, 2, false, 0>(ctx, p, Nb, pl.S, part); break;
         case 2201: launch_one<128, 320, 4, 2, 2, false, D>(ctx, p, Nb, pl.S, part); break;
+        // 64x320 tiles, 4 waves of 32x160: short-K problems of the N = 320 / 640 layers (A read once, more bytes in flight)
+        case 3200: launch_one<64, 320, 2, 2, 2, false, 0>(ctx, p, Nb, pl.S, part); break;
+        case 3300: launch_one<64, 320, 2, 2, 3, false, 0>(ctx, p, Nb, pl.S, part); break;
         default: MAA_CHECK(false, "igemm_dma2: no such (tile, stages, pipe, prefetch) instantiation");
     }
 }

@@ -159,7 +159,7 @@ void launch_igemm_dma_lean(const Ctx& ctx, const IGemm& p, int Nb);   // experim
 // second LDS-DMA engine (igemm_dma2.hip): 128x128 / 256x128 tiles, 64x64 outputs per wave, split-K finished by a
 // fixed-order reduce kernel.  `takes` and the slab size depend on the layer (K, packed N) only, never on M.
 struct Dma2Plan {
-    int cfg = -1;       // -1: not taken.  0: 128x128 / 4 waves, 1: 256x128 / 8 waves, 2: 128x320 / 8 waves
+    int cfg = -1;       // -1: not taken.  0: 128x128 / 4 waves, 1: 256x128 / 8 waves, 2: 128x320 / 8 waves, 3: 64x320 / 4 waves
     int ns = 2, pipe = 0, S = 1, pf = 0;      // LDS stages, in-wave pipelining, K slices, L2 prefetch on / off
 };
 Dma2Plan igemm_dma2_plan(const IGemm& p);

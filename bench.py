@@ -381,13 +381,22 @@ def main():
         rows = pipe.ctx.prof_end()
         result["roofline"] = roofline_of(rows, args.precision)
         dom = result["roofline"]["kernel"]
+        # HBM-side traffic per launch: measured by scripts/gpu_profile.sh on the GPU box right before this run (separate
+        # rocprofv3 PMC passes).  Accepted only if it was taken on THIS binary and launch mix: same sources (hash), same
+        # precision, and the same number of launches of the dominant kernel per DDIM step; otherwise null.
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
+            from audiogpt_amd.build import _source_hash
             with open(tpath) as f:
                 t = json.load(f)
-            # a measurement of THIS binary's launch mix only: same precision, same dominant kernel, same launches per batch
-            if t.get("precision") == args.precision and t.get("kernel") == dom and t.get("launches_per_batch") == result["roofline"]["launches"]:
-                result["roofline"]["traffic"], result["roofline"]["traffic_note"] = t["hbm_bytes_per_launch"], t["note"]
+            e = t.get("kernels", {}).get(dom)
+            mine = result["roofline"]["launches"] / float(S)
+            if e and t.get("precision") == args.precision and t.get("source_hash") == _source_hash() \
+                    and abs(e["launches_per_ddim_step"] - mine) <= 0.03 * mine:
+                result["roofline"]["traffic"] = e["hbm_bytes_per_launch"]
+                result["roofline"]["traffic_note"] = t["note"]
+            else:
+                result["roofline"]["traffic_note"] = "profiles/pmc_traffic.json does not match this binary / launch mix: not reported"
         if args.breakdown:
             for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
                 sys.stderr.write("%-28s launches %6d  ms %10.3f  TFLOP/s %8.2f  GB/s %9.1f\n" % (

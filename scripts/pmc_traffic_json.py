@@ -1,37 +1,60 @@
-"""HBM-side bytes per launch of one kernel family from the PMC summary written by scripts/gpu_profile.sh.
+"""HBM-side bytes per launch of every implicit-GEMM kernel family, from the FETCH_SIZE / WRITE_SIZE passes of
+scripts/gpu_profile.sh, stamped with what they were measured on so that bench.py can refuse stale numbers.
 
-python scripts/pmc_traffic_json.py <prof_pmc.txt> <rocprof kernel-name prefix> <bench family label> <precision> <out.json>
+    python scripts/pmc_traffic_json.py <prof_pmc.txt> <precision> <ddim steps of the PMC workload> <out.json>
 
-FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3 derived counters); on gfx950 FETCH_SIZE counts each 128-byte request as
-64 bytes, so it is doubled (MI355X_MICROARCH.md, HBM section).  The two counters come from separate passes."""
+FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3 derived counters); on gfx950 FETCH_SIZE counts each 128-byte request as 64
+bytes, so it is doubled (MI355X_MICROARCH.md, HBM section).  The two counters come from separate passes.  A bench label
+maps to one or more rocprof kernel-name prefixes (a split-K contraction is its GEMM launch + its reduce launch).
+"""
 import json
+import os
 import re
 import sys
 
-path, prefix, family, prec, out = sys.argv[1:6]
-sums = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}
-launches = {"FETCH_SIZE": 0, "WRITE_SIZE": 0}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+path, prec, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+LABELS = {  # bench.py / maa_prof label -> (rocprof kernel prefixes, prefix whose launch count is the label's)
+    "igemm_dma_bf16x3<64x64>": (["igemm_dma_kernel<64, 64"], "igemm_dma_kernel<64, 64"),
+    "igemm_dma_bf16x3<128x64>": (["igemm_dma_kernel<128, 64"], "igemm_dma_kernel<128, 64"),
+    "igemm_dma_bf16x3<128x128>": (["igemm_dma_kernel<128, 128"], "igemm_dma_kernel<128, 128"),
+    "igemm_dma2_bf16x3<128x128,splitK>": (["igemm_dma2_kernel<128, 128", "splitk_reduce_kernel"], "igemm_dma2_kernel<128, 128"),
+    "igemm_dma2_bf16x3<128x320,splitK>": (["igemm_dma2_kernel<128, 320"], "igemm_dma2_kernel<128, 320"),
+    "igemm_f32<64x64>": (["igemm_f32_kernel<64, 64"], "igemm_f32_kernel<64, 64"),
+    "igemm_f32<128x64>": (["igemm_f32_kernel<128, 64"], "igemm_f32_kernel<128, 64"),
+    "igemm_f32<128x128>": (["igemm_f32_kernel<128, 128"], "igemm_f32_kernel<128, 128"),
+}
+rows = {"FETCH_SIZE": {}, "WRITE_SIZE": {}}          # counter -> kernel name -> (launches, sum KB)
 section = None
 for line in open(path):
     if line.startswith("=="):
         section = line.split()[1]
         continue
-    if section in sums and line.startswith(prefix):
-        m = re.search(r"launches\s+(\d+)", line)
+    m = re.search(r"^(.*?)\s+grid\s+\S+\s+launches\s+(\d+)", line)
+    if section in rows and m:
         v = re.search(section + r"=([0-9.eE+-]+)", line)
-        if m and v:
-            sums[section] += float(v.group(1))
-            launches[section] += int(m.group(1))
-n = max(launches.values())
-if n == 0:
-    print("no rows match", prefix)
-    sys.exit(1)
-per_launch = (2.0 * sums["FETCH_SIZE"] / max(launches["FETCH_SIZE"], 1) + sums["WRITE_SIZE"] / max(launches["WRITE_SIZE"], 1)) * 1024.0
-json.dump({"precision": prec, "kernel_family": family, "rocprof_kernel_prefix": prefix,
-           "hbm_bytes_per_launch": per_launch, "fetch_kb_sum": sums["FETCH_SIZE"], "write_kb_sum": sums["WRITE_SIZE"],
-           "launches": n,
-           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate kernel-trace passes over 4 eager DDIM steps "
-                   "(8 latents + CFG), all launches whose kernel name starts with '%s'; FETCH_SIZE doubled per "
-                   "MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); source " % prefix + path},
+        if v:
+            n0, s0 = rows[section].get(m.group(1).strip(), (0, 0.0))
+            rows[section][m.group(1).strip()] = (n0 + int(m.group(2)), s0 + float(v.group(1)))
+kernels = {}
+for label, (prefixes, count_prefix) in LABELS.items():
+    tot, n = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}, 0
+    for c in tot:
+        for name, (ln, kb) in rows[c].items():
+            if any(name.startswith(p) for p in prefixes):
+                tot[c] += kb
+            if c == "FETCH_SIZE" and name.startswith(count_prefix):
+                n += ln
+    if n:
+        kernels[label] = {"hbm_bytes_per_launch": (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / n,
+                          "fetch_kb_sum": tot["FETCH_SIZE"], "write_kb_sum": tot["WRITE_SIZE"], "launches": n,
+                          "launches_per_ddim_step": n / float(steps)}
+from audiogpt_amd.build import _source_hash  # noqa: E402
+json.dump({"precision": prec, "source_hash": _source_hash(), "ddim_steps": steps, "kernels": kernels,
+           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate kernel-trace passes over %d eager DDIM steps of the "
+                   "benchmark batch (8 latents + CFG); HBM-side bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, "
+                   "MI355X_MICROARCH.md) + WRITE_SIZE, per launch of the labelled contraction (a split-K contraction includes "
+                   "its reduce launch); Infinity-Cache hits are counted by these counters; source %s" % (steps, path)},
           open(out, "w"), indent=1)
-print(family, "HBM-side bytes per launch: %.1f MB over %d launches" % (per_launch / 1e6, n))
+for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["launches"]):
+    print("%-40s %8.1f MB per launch  (%d launches, %.1f per DDIM step)" % (k, v["hbm_bytes_per_launch"] / 1e6, v["launches"], v["launches_per_ddim_step"]))

@@ -21,7 +21,7 @@ TOL = 2e-4
 # [, minimum K, L2 prefetch]
 VARIANTS = ["0,2,0,1", "0,2,0,4", "0,3,0,3", "0,3,1,2", "0,4,1,5", "1,2,0,2", "1,3,0,1", "1,3,1,3",
             "0,2,0,4,0,1", "0,3,0,2,0,1", "0,4,0,3,0,1", "0,4,1,2,0,1", "0,5,1,2", "1,2,0,3,0,1", "1,3,1,2,0,1",
-            "2,2,0,1", "2,2,0,3,0,1"]
+            "2,2,0,1", "2,2,0,3,0,1", "3,2,0,1", "3,3,0,2"]
 
 
 @pytest.fixture(scope="module")
@@ -111,7 +111,7 @@ def test_identity_asymmetric(ctx):
 
 
 @pytest.mark.parametrize("variant", ["0,2,0,1", "0,3,0,1", "0,3,1,1", "0,4,1,1", "1,2,0,1", "1,3,1,1", "0,2,0,1,0,1",
-                                     "0,4,1,1,0,1", "0,5,1,1", "2,2,0,1", "2,2,0,1,0,1"])
+                                     "0,4,1,1,0,1", "0,5,1,1", "2,2,0,1", "2,2,0,1,0,1", "3,3,0,1"])
 def test_one_slice_is_bit_identical_to_the_other_engines(ctx, variant):
     """Same products in the same order per accumulator: without a K split this engine, the 64x64 LDS-DMA engine and the
     register-staged engine agree bit for bit."""

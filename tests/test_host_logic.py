@@ -123,35 +123,57 @@ def test_unet_layer_plan_matches_survey_counts():
     assert abs(n_params - 160.22e6) < 0.05e6                   # 160.2 M parameters
 
 
-def test_pmc_traffic_json_reproduces_committed_number(tmp_path):
-    """Measurement tooling: profiles/r1_pmc_traffic.json (read by bench.py for roofline.traffic) is exactly what
-    scripts/pmc_traffic_json.py derives from the committed PMC summary (FETCH_SIZE doubled on gfx950, KB -> bytes)."""
+def test_pmc_traffic_derivation_and_staleness_guard(tmp_path):
+    """scripts/pmc_traffic_json.py on a synthetic PMC summary: FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B),
+    KB -> bytes, a split-K contraction = its GEMM launches + its reduce launches, per-step launch counts and the source hash
+    that bench.py uses to refuse numbers taken on another binary."""
     import json
     import subprocess
     import sys
-    committed = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+
+    from audiogpt_amd.build import _source_hash
+    txt = tmp_path / "pmc.txt"
+    txt.write_text(
+        "== FETCH_SIZE GRBM_GUI_ACTIVE  (4 DDIM steps)\n"
+        "igemm_dma_kernel<64, 64, 2, 2, 4>                  grid 249600    launches   200  FETCH_SIZE=1000000  GRBM_GUI_ACTIVE=1\n"
+        "igemm_dma_kernel<64, 64, 2, 2, 4>                  grid 125440    launches    64  FETCH_SIZE=320000  GRBM_GUI_ACTIVE=1\n"
+        "igemm_dma2_kernel<128, 128, 2, 2, 4, true, 0>      grid 64000     launches    40  FETCH_SIZE=400000  GRBM_GUI_ACTIVE=1\n"
+        "splitk_reduce_kernel<1>                            grid 128000    launches    40  FETCH_SIZE=200000  GRBM_GUI_ACTIVE=1\n"
+        "== WRITE_SIZE GRBM_GUI_ACTIVE  (4 DDIM steps)\n"
+        "igemm_dma_kernel<64, 64, 2, 2, 4>                  grid 249600    launches   200  WRITE_SIZE=500000  GRBM_GUI_ACTIVE=1\n"
+        "igemm_dma_kernel<64, 64, 2, 2, 4>                  grid 125440    launches    64  WRITE_SIZE=100000  GRBM_GUI_ACTIVE=1\n"
+        "igemm_dma2_kernel<128, 128, 2, 2, 4, true, 0>      grid 64000     launches    40  WRITE_SIZE=640000  GRBM_GUI_ACTIVE=1\n"
+        "splitk_reduce_kernel<1>                            grid 128000    launches    40  WRITE_SIZE=160000  GRBM_GUI_ACTIVE=1\n")
     out = str(tmp_path / "t.json")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic_json.py"),
-                        os.path.join(ROOT, "profiles", "r1_bf16x3_pmc_fetch_write.txt"), committed["rocprof_kernel_prefix"],
-                        committed["kernel_family"], committed["precision"], out], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic_json.py"), str(txt), "bf16x3", "4", out],
+                       capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    again = json.load(open(out))
-    assert again["launches"] == committed["launches"]
-    assert abs(again["hbm_bytes_per_launch"] - committed["hbm_bytes_per_launch"]) < 1.0
-    expect = (2.0 * committed["fetch_kb_sum"] + committed["write_kb_sum"]) / committed["launches"] * 1024.0
-    assert abs(committed["hbm_bytes_per_launch"] - expect) < 1.0
+    t = json.load(open(out))
+    assert t["precision"] == "bf16x3" and t["source_hash"] == _source_hash() and t["ddim_steps"] == 4
+    k = t["kernels"]["igemm_dma_bf16x3<64x64>"]
+    assert k["launches"] == 264 and k["launches_per_ddim_step"] == 66.0
+    assert abs(k["hbm_bytes_per_launch"] - (2 * 1320000 + 600000) * 1024.0 / 264) < 1e-6
+    k2 = t["kernels"]["igemm_dma2_bf16x3<128x128,splitK>"]
+    assert k2["launches"] == 40 and abs(k2["hbm_bytes_per_launch"] - (2 * 600000 + 800000) * 1024.0 / 40) < 1e-6
 
 
-def test_bench_line_contract_of_the_committed_run():
-    """The last bench line of the round carries every field of the driver's contract plus roofline and cpu_baseline."""
+def test_bench_line_contract_of_a_gpu_run():
+    """A bench line measured on the MI355X this round (profiles/r2_bf16x3_bench.json, written by scripts/gpu_profile.sh)
+    carries every field of the driver's contract plus roofline, cpu_baseline and the secondary workloads, and its
+    arithmetic is self-consistent."""
     import json
-    d = json.load(open(os.path.join(ROOT, "profiles", "r1_bf16x3_bench_final.json")))
+    path = os.path.join(ROOT, "profiles", "r2_bf16x3_bench.json")
+    if not os.path.exists(path):
+        import pytest
+        pytest.skip("no round-2 bench line committed yet")
+    d = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] > 0
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     assert abs(d["value"] - d["config"]["audio_seconds_per_step"] / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
