@@ -230,229 +230,6 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const IGemm p, int ntiles
     igemm_epilogue<MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lrow, lk, 0, Nb, rpb);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// Software-pipelined variant for the 128x64 tile (EXPERIMENTAL, MAA_DMA_PIPE=1, default off).  Measured at the end of
-// round 1: bit-identical to the other engines (test_dma_engine_bit_identical under MAA_DMA_PIPE=1 MAA_FORCE_CFG=1), but no
-// faster -- 20-step run 247.4 ms vs 245.9 ms on its own shapes, 275 ms when forced onto every shape: hiding the phases
-// inside a wave does not move the per-CU throughput, so the limit is not instruction scheduling.  Each wave owns 64x32 outputs = two accumulator chains, so single-issue instructions can sit between its
-// MFMAs at ~6 cycles each instead of the ~43 a filler costs inside one chain.  Per K chunk c a wave runs
-//   P1(c): the 6 MFMAs of k-step 0 (fragments read during chunk c-1), the fragment reads of k-step 1 behind the first two
-//          s_waitcnt vmcnt (own copies of chunk c+1 landed) ; s_barrier  = B(c+1)
-//   P2(c): issue the fragment reads of chunk c+1 / k-step 0, then the 6 MFMAs of k-step 1, each followed by one of
-//          this wave's 6 LDS-DMA copies of chunk c+NS-1 into the stage chunk c-1 used (free: every wave consumed
-//          chunk c-1 before it reached B(c+1)).
-// So the barrier skew, the LDS read latency and the DMA issue all hide under MFMAs of the same wave, instead of being
-// serial phases that every wave of the CU executes at the same time.  Products and their order per
-// accumulator are those of the other engines: results stay bit-identical.
-template <int NS>
-__global__ __launch_bounds__(NT) void igemm_dma_pipe_kernel(const IGemm p, int ntiles, int Nb) {
-    constexpr int BM = 128, BN = 64, WGN = 2;
-    constexpr int WTM = 64, WTN = 32, MI = 2;
-    constexpr int ROWS = BM + BN;
-    constexpr int STAGE = ROWS * 128;
-    constexpr int IPW = ROWS / 32;             // 6 copies per wave and chunk
-    static_assert(NS >= 3 && (NS - 3) * IPW <= 63, "stages");
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    int bid = blockIdx.x;
-    {
-        const int nblk = gridDim.x, xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
-        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    }
-    int nt, mt;
-    if (p.m_fastest) {
-        const int mtiles = gridDim.x / ntiles;
-        mt = bid % mtiles;
-        nt = bid / mtiles;
-    } else {
-        nt = bid % ntiles;
-        mt = bid / ntiles;
-    }
-    const int m0 = mt * BM, n0 = nt * BN;
-
-    const int Ctot = p.C1;
-    const int rpb = p.Hout * p.Wout;
-    const int Hlim = p.Hin << p.up, Wlim = p.Win << p.up;
-    const int taps = p.KH * p.KW;
-    const char* zero = reinterpret_cast<const char*>(p.zeros);
-
-    bool is_a[IPW];
-    int a_b[IPW], a_iy0[IPW], a_ix0[IPW];
-    const char* a_slot[IPW];
-    const char* src[IPW];
-    bool ok[IPW];
-#pragma unroll
-    for (int j = 0; j < IPW; ++j) {
-        const int row = 8 * (wid * IPW + j) + (lane >> 3);
-        const int slot = (lane & 7) ^ ((row >> 1) & 7);
-        is_a[j] = 8 * (wid * IPW + j) < BM;
-        a_b[j] = -1;
-        a_iy0[j] = a_ix0[j] = 0;
-        a_slot[j] = reinterpret_cast<const char*>(p.a1) + slot * 16;
-        src[j] = zero;
-        ok[j] = false;
-        if (is_a[j]) {
-            const int m = m0 + row;
-            if (m < p.M) {
-                const int b = m / rpb;
-                const int rem = m - b * rpb;
-                const int oy = rem / p.Wout;
-                a_b[j] = b;
-                a_iy0[j] = oy * p.sh - p.ph;
-                a_ix0[j] = (rem - oy * p.Wout) * p.sw - p.pw;
-            }
-        } else {
-            const int n = n0 + row - BM;
-            ok[j] = n < Nb;
-            src[j] = reinterpret_cast<const char*>(p.b) + (long long)(ok[j] ? n : 0) * p.ldb * 4 + slot * 16;
-        }
-    }
-    auto set_tap = [&](int tap) {
-        const int ky = tap / p.KW, kx = tap - ky * p.KW;
-#pragma unroll
-        for (int j = 0; j < IPW; ++j)
-            if (is_a[j]) {
-                int iy = a_iy0[j] + ky * p.dh, ix = a_ix0[j] + kx * p.dw;
-                const bool v = a_b[j] >= 0 && iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim;
-                iy >>= p.up;
-                ix >>= p.up;
-                const long long off = v ? ((long long)a_b[j] * p.Hin + iy) * p.Win + ix : 0;
-                ok[j] = v;
-                src[j] = a_slot[j] + off * p.lda1 * 4;
-            }
-    };
-    int g_tap = 0, g_ci = 0;
-    bool past = false;
-    // one copy (8 rows x 128 B) of the chunk at (g_tap, g_ci) into `sbase` (this wave's slice of a stage)
-    auto issue1 = [&](char* sbase, int j) {
-        const int k0 = g_tap * Ctot + g_ci;
-        const int off = is_a[j] ? g_ci : k0;
-        const bool live = ok[j] && !past && (is_a[j] || k0 < p.K);
-        const char* g = live ? src[j] + (long long)off * 4 : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(sbase + j * 1024), 16, 0, 0);
-    };
-    auto advance = [&]() {
-        g_ci += BK;
-        if (g_ci >= Ctot) {
-            g_ci = 0;
-            ++g_tap;
-            if (g_tap < taps)
-                set_tap(g_tap);
-            else
-                past = true;
-        }
-    };
-
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
-
-    const int wm = wid / WGN, wn = wid - wm * WGN;
-    const int lrow = lane & 31, lk = lane >> 5;
-    const int swz = (lrow >> 1) & 7;
-    const int a_row = (wm * WTM + lrow) * 128, b_row = (BM + wn * WTN + lrow) * 128;
-    int so[2][2];                              // [plane][k-step] byte offset of this lane's 16-byte piece
-#pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) so[pl][ks] = ((pl * 4 + ks * 2 + lk) ^ swz) << 4;
-
-    // fragments of one k-step: A hi/lo for the wave's two 32-row blocks, B hi/lo
-    struct Frags {
-        bf16x8 ah0, ah1, al0, al1, bh, bl;
-    };
-    auto read_frags = [&](const char* base, int ks, Frags& f) {
-        f.al0 = *reinterpret_cast<const bf16x8*>(base + a_row + so[1][ks]);
-        f.bh = *reinterpret_cast<const bf16x8*>(base + b_row + so[0][ks]);
-        f.al1 = *reinterpret_cast<const bf16x8*>(base + a_row + 4096 + so[1][ks]);
-        f.ah0 = *reinterpret_cast<const bf16x8*>(base + a_row + so[0][ks]);
-        f.bl = *reinterpret_cast<const bf16x8*>(base + b_row + so[1][ks]);
-        f.ah1 = *reinterpret_cast<const bf16x8*>(base + a_row + 4096 + so[0][ks]);
-    };
-
-    const int nchunks = (p.K + BK - 1) / BK;
-    set_tap(0);
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) {
-        char* sb = smem + s * STAGE + wid * (IPW * 1024);
-#pragma unroll
-        for (int j = 0; j < IPW; ++j) issue1(sb, j);
-        advance();
-    }
-    wait_vmcnt<(NS - 2) * IPW>();
-    __builtin_amdgcn_s_barrier();              // B(0): chunk 0 is in LDS
-    Frags f0, f1;
-    read_frags(smem, 0, f0);
-    int st = 0;                                // stage of chunk c
-    for (int c = 0; c < nchunks; ++c) {
-        const char* cur = smem + st * STAGE;
-        const int st_next = st + 1 == NS ? 0 : st + 1;
-        const int st_fill = st == 0 ? NS - 1 : st - 1;
-        // ---- P1(c): the k-step-1 reads go out behind the first two MFMAs, so the (uncounted) lgkmcnt wait the
-        // compiler puts in front of the first MFMA only covers fragments that landed a phase ago
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.al0, f0.bh, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.al1, f0.bh, acc1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(cur, 1, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.ah0, f0.bl, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.ah1, f0.bl, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.ah0, f0.bh, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.ah1, f0.bh, acc1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<(NS - 3) * IPW>();          // this wave's copies of chunk c+1 have landed
-        __builtin_amdgcn_s_barrier();          // B(c+1): everybody's have, and everybody consumed chunk c-1
-        // ---- P2(c)  (the reads of the next chunk go out behind the first two MFMAs, for the same reason as in P1)
-        char* fb = smem + st_fill * STAGE + wid * (IPW * 1024);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.al0, f1.bh, acc0, 0, 0, 0);
-        issue1(fb, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.al1, f1.bh, acc1, 0, 0, 0);
-        issue1(fb, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(smem + st_next * STAGE, 0, f0);      // (past the last chunk: zeros / stale data, never multiplied)
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.ah0, f1.bl, acc0, 0, 0, 0);
-        issue1(fb, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.ah1, f1.bl, acc1, 0, 0, 0);
-        issue1(fb, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.ah0, f1.bh, acc0, 0, 0, 0);
-        issue1(fb, 4);
-        __builtin_amdgcn_sched_barrier(0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.ah1, f1.bh, acc1, 0, 0, 0);
-        issue1(fb, 5);
-        __builtin_amdgcn_sched_barrier(0);
-        advance();
-        st = st_next;
-    }
-    wait_vmcnt<0>();
-
-    f32x16 acc[MI][1];
-    acc[0][0] = acc0;
-    acc[1][0] = acc1;
-    igemm_epilogue<MI, 1>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lrow, lk, 0, Nb, rpb);
-}
-
-template <int NS>
-void launch_pipe(const Ctx& ctx, const IGemm& p, int Nb) {
-    const int ncols = p.N * (p.geglu ? 2 : 1);
-    const int mtiles = (p.M + 127) / 128, ntiles = (ncols + 63) / 64;
-    dim3 grid((unsigned)((long long)mtiles * ntiles));
-    constexpr size_t lds = (size_t)NS * 192 * 128;
-    auto kern = igemm_dma_pipe_kernel<NS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, p, ntiles, Nb);
-}
-
 template <int BM, int BN, int WGM, int WGN, int NS>
 void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
     const int ncols = p.N * (p.geglu ? 2 : 1);
@@ -500,32 +277,25 @@ void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
     // though the L2-warm micro-benchmark prefers more workgroups per CU: 64x64 -> 4 stages (64 KB, 2 workgroups/CU),
     // 128x64 -> 3 (72 KB, 2/CU), 128x128 -> 2 (64 KB, 2/CU).  In-pipeline A/B (20 DDIM steps + decode, ms): stages
     // (128x128, 128x64, 64x64) = (2,3,4) 234.0 | (2,2,2) +3.7 % | (2,3,5) +0.9 % | (2,3,6) +18.6 % | (2,4,4) +7.5 % | (3,3,4) +3.8 %.
-    const int ns = ns_env ? ns_env : (cfg == 2 ? 4 : cfg == 1 ? 3 : 2);
+    // Round 2: the long-K contractions moved to igemm_dma2.hip; on what is left to the 64x64 tile (K = 320 / 640 linears,
+    // ten or twenty chunks) two stages -- five workgroups per CU instead of two -- win: in-pipeline (2,3,2) -2.3 % vs (2,3,4)
+    // (profiles/r2_dma2_inpipe_probes.txt).
+    const int ns = ns_env ? ns_env : (cfg == 2 ? 2 : cfg == 1 ? 3 : 2);
     (void)ncols;
     switch (cfg) {
         case 0:
             if (ns >= 3) launch_one<128, 128, 2, 2, 3>(ctx, p, Nb);
             else launch_one<128, 128, 2, 2, 2>(ctx, p, Nb);
             break;
-        case 1: {
-            static const int pipe = std::getenv("MAA_DMA_PIPE") ? std::atoi(std::getenv("MAA_DMA_PIPE")) : 0;   // experimental
-            if (pipe == 4 && !p.geglu) launch_pipe<4>(ctx, p, Nb);
-            else if (pipe && !p.geglu) launch_pipe<3>(ctx, p, Nb);
-            else if (ns >= 3) launch_one<128, 64, 2, 2, 3>(ctx, p, Nb);
+        case 1:
+            if (ns >= 3) launch_one<128, 64, 2, 2, 3>(ctx, p, Nb);
             else launch_one<128, 64, 2, 2, 2>(ctx, p, Nb);
             break;
-        }
-        default: {
-            static const bool lean = std::getenv("MAA_DMA_LEAN") != nullptr;        // experimental, see igemm_dma_lean_kernel
-            if (lean && !p.geglu && !p.dbg) {
-                launch_igemm_dma_lean(ctx, p, Nb);
-                break;
-            }
+        default:
             if (ns >= 4) launch_one<64, 64, 2, 2, 4>(ctx, p, Nb);
             else if (ns == 3) launch_one<64, 64, 2, 2, 3>(ctx, p, Nb);
             else launch_one<64, 64, 2, 2, 2>(ctx, p, Nb);
             break;
-        }
     }
 }
 

@@ -23,6 +23,10 @@
 // masked rows point at the zero page with a step of 0; pointers are rebuilt only when the tap changes), the wave index
 // is scalar so LDS destinations are SALU, and the A / B role of a copy is a compile-time property of its index.
 // PIPE = true additionally software-pipelines the fragment reads inside a wave (barrier in mid-chunk).
+// Workgroups are persistent: the grid is capped at what the chip holds at once and a workgroup runs its (slice, tile)
+// items as one continuous stream of K chunks, so an item's cold start and store tail overlap its neighbours' MFMA work.
+// (Tried and dropped, profiles/r2_dma2_sweep2*.txt: touching the lines of the chunk six ahead with 4-byte LDS-DMAs as an
+//  L2 prefetch -- 0 to -3 % in the pipeline; a 64x320 tile for the short-K layers -- 14 % slower in the pipeline.)
 #include "igemm_epilogue.h"
 
 #include <cstdio>
@@ -56,9 +60,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE, int PF>
+template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm p, int ntiles, int tiles, int Nb,
-                                                                     int cps, float* __restrict__ part) {
+                                                                     int cps, int items, float* __restrict__ part) {
     constexpr int NW = WGM * WGN, NTH = 64 * NW;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
@@ -66,42 +70,37 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
     constexpr int STAGE = ROWS * 128;                  // bytes
     constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // copies (8 rows x 128 B) per wave and chunk: A rows, B rows
     constexpr int IPW = AI + BI;
-    // L2 prefetch (PF > 0): every chunk, each lane touches one 128-byte line of the tile rows of the chunk PF ahead with a
-    // 4-byte LDS-DMA into a scratch area (no VGPR is written, so nothing waits for it).  The copies of that chunk, issued
-    // PF - NS + 1 iterations later, then hit L2 instead of paying the MALL / HBM latency on the critical path: the LDS
-    // stages alone cannot hold the latency x bandwidth product (42 B/clk x ~2900 clk = 120 KB for 128x128 tiles).
-    constexpr int PFI = PF > 0 ? (ROWS + 64 * NW - 1) / (64 * NW) : 0;      // prefetch instructions per wave and chunk
-    constexpr int VMI = IPW + PFI;                                          // VM operations per wave and chunk
-    constexpr int VM_TAIL = PFI;        // prefetches issued after the copies of the same chunk (younger than them)
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0 && BM % 64 == 0, "copy assignment");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "copy assignment");
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % 32 == 0, "tile");
-    static_assert(NS >= (PIPE ? 3 : 2) && (NS - 2) * VMI + VM_TAIL <= 63, "stages / vmcnt field");
-    static_assert(PF == 0 || PF >= NS, "prefetch distance must exceed the copy queue");
-    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NS][ROWS][128] (+ [NW][PFI][256] prefetch scratch)
+    static_assert(NS >= (PIPE ? 3 : 2) && (NS - 2) * IPW <= 63, "stages / vmcnt field");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NS][ROWS][128]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- workgroup -> (K slice, tile).  An XCD (workgroup b runs on XCD b % 8) gets a contiguous range of
-    // [slice][m tile][n tile], n fastest: the tiles sharing A rows / weight rows of one slice meet in one L2, and a
-    // weight slice is fetched by 8 / S XCDs instead of all eight.
-    int bid = blockIdx.x;
+    // ---- work items = (K slice, tile) pairs, `items` of them in the order [slice][m tile][n tile], n fastest.  An XCD
+    // (workgroup b runs on XCD b % 8) owns a contiguous range of items -- the tiles sharing A rows / weight rows of one
+    // slice meet in one L2, and a weight slice is fetched by 8 / S XCDs instead of all eight -- and its workgroups walk
+    // that range with a stride of their number, so at any time they work on neighbouring items.
+    // The grid may be smaller than `items` (persistent workgroups): a workgroup then runs its items as ONE stream of K
+    // chunks -- the copies of the next item's first chunks are in flight while this item's epilogue runs, so the cold
+    // start (address set-up, first-touch latency of the operands) and the store tail of an item overlap the neighbours'
+    // MFMA work instead of adding up per round of workgroups.
+    int w_lo, w_cnt, w_step;
     {
-        const int nblk = gridDim.x, xcd = bid & 7, qq = nblk >> 3, rr = nblk & 7;
-        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+        const int G = gridDim.x, xcd = blockIdx.x & 7, qq = items >> 3, rr = items & 7;
+        w_lo = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
+        w_cnt = qq + (xcd < rr ? 1 : 0);
+        w_step = (G - xcd + 7) >> 3;
     }
-    const int slice = bid / tiles;
-    const int tile = bid - slice * tiles;
-    const int mt = tile / ntiles, nt = tile - mt * ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int w_first = (int)(blockIdx.x >> 3);
+    if (w_first >= w_cnt) return;              // (never when grid <= items; uniform for the workgroup)
 
     const int Ctot = p.C1;                     // single split32 source (checked by the launcher)
     const int cpt = Ctot / BK;                 // chunks per tap
     const int rpb = p.Hout * p.Wout;
     const int Hlim = p.Hin << p.up, Wlim = p.Win << p.up;
     const int nchunks = p.K / BK;
-    const int c_begin = slice * cps;
-    const int c_end = min(nchunks, c_begin + cps);
     const char* zero = reinterpret_cast<const char*>(p.zeros);
 
     // ---- copies.  Copy q of an operand covers its rows 8q .. 8q+7; this wave issues q = j NW + wid.  Lane i moves the
@@ -112,24 +111,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
     int a_b[AI], a_iy0[AI], a_ix0[AI];
     const char* gpa[AI];
     unsigned inca[AI];
-#pragma unroll
-    for (int j = 0; j < AI; ++j) {
-        const int m = m0 + 8 * (j * NW + wid) + r8;
-        a_b[j] = -1;
-        a_iy0[j] = a_ix0[j] = 0;
-        if (m < p.M) {
-            const int b = m / rpb;
-            const int rem = m - b * rpb;
-            const int oy = rem / p.Wout;
-            a_b[j] = b;
-            a_iy0[j] = oy * p.sh - p.ph;
-            a_ix0[j] = (rem - oy * p.Wout) * p.sw - p.pw;
-        }
-        gpa[j] = zero;
-        inca[j] = 0;
-    }
+    const char* gpb[BI];
+    unsigned incb = 0;
     const char* a_base = reinterpret_cast<const char*>(p.a1) + slot_b;
-    auto set_tap = [&](int tap, int ci) {
+    int g_w = w_first, g_end = 0, g_tap = 0, g_ci = 0, g_c = 0;      // the item / chunk the next copies belong to
+    auto set_tap = [&](int tap, int ci) __attribute__((always_inline)) {
         const int ky = tap / p.KW, kx = tap - ky * p.KW;
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
@@ -142,87 +128,42 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
             inca[j] = v ? BK * 4 : 0;
         }
     };
-    // weight rows past the last one are clamped to it: their columns are computed on real data and never stored
-    // (a column of the product depends on its own weight row only), which keeps the step of every B copy uniform
-    const char* gpb[BI];
-    unsigned incb = BK * 4;
+    // point the copies at the first chunk of item w
+    auto setup_item = [&](int w) __attribute__((always_inline)) {
+        const int item = w_lo + w;
+        const int slice = item / tiles, tile = item - slice * tiles;
+        const int mt = tile / ntiles, nt = tile - mt * ntiles;
+        const int m0 = mt * BM, n0 = nt * BN;
+        const int c_begin = slice * cps;
+        g_end = min(nchunks, c_begin + cps);
+        g_c = c_begin;
+        g_tap = c_begin / cpt;
+        g_ci = (c_begin - g_tap * cpt) * BK;
 #pragma unroll
-    for (int j = 0; j < BI; ++j) {
-        const int n = min(n0 + 8 * (j * NW + wid) + r8, Nb - 1);
-        gpb[j] = reinterpret_cast<const char*>(p.b) + ((long long)n * p.ldb + (long long)c_begin * BK) * 4 + slot_b;
-    }
-    // ---- prefetch lines: line 64 (q NW + wid) + lane of the list [A rows | B rows] of the tile
-    int pf_b[PFI > 0 ? PFI : 1], pf_iy0[PFI > 0 ? PFI : 1], pf_ix0[PFI > 0 ? PFI : 1];
-    const char* pfp[PFI > 0 ? PFI : 1];
-    unsigned pfinc[PFI > 0 ? PFI : 1];
-    int pf_c = c_begin + PF, pf_tap = 0, pf_ci = 0;
-    auto pf_set_tap = [&]() {
-        const int ky = pf_tap / p.KW, kx = pf_tap - ky * p.KW;
-#pragma unroll
-        for (int q = 0; q < PFI; ++q) {
-            if (64 * (q * NW + wid) < BM) {            // (wave-uniform)
-                int iy = pf_iy0[q] + ky * p.dh, ix = pf_ix0[q] + kx * p.dw;
-                const bool v = pf_b[q] >= 0 && iy >= 0 && iy < Hlim && ix >= 0 && ix < Wlim;
-                iy >>= p.up;
-                ix >>= p.up;
-                const long long pos = ((long long)pf_b[q] * p.Hin + iy) * p.Win + ix;
-                pfp[q] = v ? reinterpret_cast<const char*>(p.a1) + (pos * p.lda1 + pf_ci) * 4 : zero;
-                pfinc[q] = v ? BK * 4 : 0;
+        for (int j = 0; j < AI; ++j) {
+            const int m = m0 + 8 * (j * NW + wid) + r8;
+            a_b[j] = -1;
+            a_iy0[j] = a_ix0[j] = 0;
+            if (m < p.M) {
+                const int b = m / rpb;
+                const int rem = m - b * rpb;
+                const int oy = rem / p.Wout;
+                a_b[j] = b;
+                a_iy0[j] = oy * p.sh - p.ph;
+                a_ix0[j] = (rem - oy * p.Wout) * p.sw - p.pw;
             }
         }
+        set_tap(g_tap, g_ci);
+        // weight rows past the last one are clamped to it: their columns are computed on real data and never stored
+        // (a column of the product depends on its own weight row only), which keeps the step of every B copy uniform
+#pragma unroll
+        for (int j = 0; j < BI; ++j) {
+            const int n = min(n0 + 8 * (j * NW + wid) + r8, Nb - 1);
+            gpb[j] = reinterpret_cast<const char*>(p.b) + ((long long)n * p.ldb + (long long)c_begin * BK) * 4 + slot_b;
+        }
+        incb = BK * 4;
     };
-    if constexpr (PFI > 0) {
-        pf_tap = pf_c / cpt;
-        pf_ci = (pf_c - pf_tap * cpt) * BK;
-#pragma unroll
-        for (int q = 0; q < PFI; ++q) {
-            const int li = 64 * (q * NW + wid) + lane;
-            pf_b[q] = -1;
-            pf_iy0[q] = pf_ix0[q] = 0;
-            pfp[q] = zero;
-            pfinc[q] = 0;
-            if (li < BM) {
-                const int m = m0 + li;
-                if (m < p.M) {
-                    const int b = m / rpb;
-                    const int rem = m - b * rpb;
-                    const int oy = rem / p.Wout;
-                    pf_b[q] = b;
-                    pf_iy0[q] = oy * p.sh - p.ph;
-                    pf_ix0[q] = (rem - oy * p.Wout) * p.sw - p.pw;
-                }
-            } else if (li < ROWS && pf_c < c_end) {
-                const int n = min(n0 + li - BM, Nb - 1);
-                pfp[q] = reinterpret_cast<const char*>(p.b) + ((long long)n * p.ldb + (long long)pf_c * BK) * 4;
-                pfinc[q] = BK * 4;
-            }
-        }
-        if (pf_c < c_end) pf_set_tap();
-    }
-    auto prefetch = [&]() {
-        if constexpr (PFI > 0) {
-            static_for<0, PFI>([&](auto qc) {
-                constexpr int q = decltype(qc)::value;
-                __builtin_amdgcn_global_load_lds((gptr_t)pfp[q], (lptr_t)(smem + NS * STAGE + (wid * PFI + q) * 256), 4, 0, 0);
-                pfp[q] += pfinc[q];
-            });
-            ++pf_c;
-            pf_ci += BK;
-            if (pf_c >= c_end) {
-#pragma unroll
-                for (int q = 0; q < PFI; ++q) {
-                    pfp[q] = zero;
-                    pfinc[q] = 0;
-                }
-            } else if (pf_ci >= Ctot) {
-                pf_ci = 0;
-                ++pf_tap;
-                pf_set_tap();
-            }
-        }
-    };
-    int g_tap = c_begin / cpt, g_ci = (c_begin - g_tap * cpt) * BK, g_c = c_begin;
-    auto kill = [&]() {           // chunks past the slice: copies still issue (uniform vmcnt arithmetic), from the zero page
+    auto kill = [&]() __attribute__((always_inline)) {           // past the last item: copies still issue (uniform vmcnt arithmetic), from the zero page
 #pragma unroll
         for (int j = 0; j < AI; ++j) {
             gpa[j] = zero;
@@ -232,11 +173,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
         for (int j = 0; j < BI; ++j) gpb[j] = zero;
         incb = 0;
     };
-    auto advance = [&]() {
+    auto advance = [&]() __attribute__((always_inline)) {
         ++g_c;
         g_ci += BK;
-        if (g_c >= c_end) {
-            kill();
+        if (g_c >= g_end) {
+            g_w += w_step;
+            if (g_w < w_cnt)
+                setup_item(g_w);
+            else
+                kill();
         } else if (g_ci >= Ctot) {
             g_ci = 0;
             ++g_tap;
@@ -244,7 +189,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
         }
     };
     // copy j of this wave's share of a chunk into stage `st` (j < AI: A rows, else B rows)
-    auto copy1 = [&](int st, auto jc) {
+    auto copy1 = [&](int st, auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         char* sb = smem + st * STAGE + wid * 1024;
         if constexpr (j < AI) {
@@ -256,19 +201,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
             gpb[jb] += incb;
         }
     };
-    auto issue = [&](int st) {
+    auto issue = [&](int st) __attribute__((always_inline)) {
         static_for<0, IPW>([&](auto jc) { copy1(st, jc); });
         advance();
-        prefetch();
     };
 
     f32x16 acc[MI][NI];
+    auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
 
     const int wm = wid / WGN, wn = wid - wm * WGN;
     const int lrow = lane & 31, lk = lane >> 5;
@@ -283,7 +230,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
     struct Frags {
         bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
     };
-    auto read_frags = [&](const char* base, int ks, Frags& f) {
+    auto read_frags = [&](const char* base, int ks, Frags& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) f.al[i] = *reinterpret_cast<const bf16x8*>(base + a_row + i * 4096 + slot_off[1][ks]);
 #pragma unroll
@@ -294,7 +241,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
         for (int j = 0; j < NI; ++j) f.bl[j] = *reinterpret_cast<const bf16x8*>(base + b_row + j * 4096 + slot_off[1][ks]);
     };
     // the 3 MI NI MFMAs of one k-step; term-major, so the three products of an accumulator are MI NI - 1 MFMAs apart
-    auto mma = [&](const Frags& f) {
+    auto mma = [&](const Frags& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -309,21 +256,52 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
             for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
     };
 
-    if (g_c < c_end)
-        set_tap(g_tap, g_ci);
-    else
-        kill();
-    const int nloc = c_end - c_begin;          // chunks of this slice (>= 1 by construction of the grid)
+    // ---- the item whose chunks are being multiplied
+    int c_w = w_first, c_rem = 0;
+    auto item_chunks = [&](int w) __attribute__((always_inline)) {
+        const int slice = (w_lo + w) / tiles;
+        return min(nchunks, (slice + 1) * cps) - slice * cps;
+    };
+    // epilogue (or slab store) of the finished item, then on to the next; false: this workgroup is done
+    auto finish_item = [&]() __attribute__((always_inline)) {
+        const int item = w_lo + c_w;
+        const int slice = item / tiles, tile = item - slice * tiles;
+        const int mt = tile / ntiles, nt = tile - mt * ntiles;
+        if (part == nullptr) {
+            igemm_epilogue<MI, NI>(p, acc, mt * BM + wm * WTM, nt * BN + wn * WTN, lrow, lk, 0, Nb, rpb);
+        } else {
+            // slab of this (slice, tile): [MI NI blocks][4 register quads][NTH threads][4 floats] -- every store
+            // instruction of a wave writes 1 KB contiguous
+            float* pp = part + ((long long)item * (MI * NI * 4) * NTH + tid) * 4;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(pp + (long long)((i * NI + j) * 4 + q) * NTH * 4) = v;
+                    }
+        }
+        zero_acc();
+        c_w += w_step;
+        if (c_w >= w_cnt) return false;
+        c_rem = item_chunks(c_w);
+        return true;
+    };
+
+    setup_item(g_w);
+    c_rem = item_chunks(c_w);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
 
     if constexpr (!PIPE) {
-        // Chunk c lives in stage c % NS.  Per chunk: wait until this wave's copies of chunk c have landed (the NS-2
-        // younger chunks stay in flight), barrier (everybody's copies of chunk c are in LDS and everybody is done
-        // reading chunk c-1), refill the stage chunk c-1 used with chunk c+NS-1, then read + multiply chunk c.
-#pragma unroll
-        for (int s = 0; s < NS - 1; ++s) issue(s);
+        // Chunk c of the stream lives in stage c % NS.  Per chunk: wait until this wave's copies of chunk c have landed
+        // (the NS-2 younger chunks stay in flight), barrier (everybody's copies of chunk c are in LDS and everybody is
+        // done reading chunk c-1), refill the stage chunk c-1 used with chunk c+NS-1, then read + multiply chunk c.
         int st = 0, st_fill = NS - 1;
-        for (int c = 0; c < nloc; ++c) {
-            wait_vmcnt<(NS - 2) * VMI + VM_TAIL>();
+        for (;;) {
+            wait_vmcnt<(NS - 2) * IPW>();
             __builtin_amdgcn_s_barrier();
             if (!(p.dbg & 2)) issue(st_fill);
             if (!(p.dbg & 1)) {
@@ -336,6 +314,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
             }
             st = st + 1 == NS ? 0 : st + 1;
             st_fill = st_fill + 1 == NS ? 0 : st_fill + 1;
+            if (--c_rem == 0)
+                if (!finish_item()) break;
         }
     } else {
         // Software-pipelined: the barrier sits in the middle of a chunk's MFMAs, so the fragment reads of the next
@@ -345,14 +325,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
         //   P2(c): reads of (c+1, k-step 0) go out, then the MFMAs of (c, k-step 1), each followed by one of this
         //          wave's copies of chunk c+NS-1 into the stage chunk c-1 used (every wave consumed chunk c-1 -- its
         //          last reads fed the MFMAs of P2(c-1) -- before it reached B(c+1)).
-#pragma unroll
-        for (int s = 0; s < NS - 1; ++s) issue(s);
-        wait_vmcnt<(NS - 2) * VMI + VM_TAIL>();
+        wait_vmcnt<(NS - 2) * IPW>();
         __builtin_amdgcn_s_barrier();              // chunk 0 is in LDS
         Frags f0, f1;
         read_frags(smem, 0, f0);
         int st = 0;
-        for (int c = 0; c < nloc; ++c) {
+        for (;;) {
             const char* cur = smem + st * STAGE;
             const int st_next = st + 1 == NS ? 0 : st + 1;
             const int st_fill = st == 0 ? NS - 1 : st - 1;
@@ -360,12 +338,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
             __builtin_amdgcn_sched_barrier(0);
             mma(f0);
             __builtin_amdgcn_sched_barrier(0);
-            wait_vmcnt<(NS - 3) * VMI + VM_TAIL>();    // this wave's copies of chunk c+1 have landed
+            wait_vmcnt<(NS - 3) * IPW>();          // this wave's copies of chunk c+1 have landed
             __builtin_amdgcn_s_barrier();          // B(c+1): everybody's have, and everybody consumed chunk c-1
             read_frags(smem + st_next * STAGE, 0, f0);      // (past the last chunk: zeros, never multiplied)
             __builtin_amdgcn_sched_barrier(0);
             // MFMAs of k-step 1 interleaved with the IPW copies
-            static_assert(3 * MI * NI >= IPW, "not enough MFMAs to carry the copies");
             static_for<0, 3 * MI * NI>([&](auto xc) {
                 constexpr int x = decltype(xc)::value;
                 constexpr int t = x / (MI * NI), i = (x % (MI * NI)) / NI, j = x % NI;
@@ -378,29 +355,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
                 if constexpr (x < IPW) copy1(st_fill, xc);
                 __builtin_amdgcn_sched_barrier(0);
             });
+            if constexpr (IPW > 3 * MI * NI)          // (small tiles: more copies than MFMAs to carry them)
+                static_for<3 * MI * NI, IPW>([&](auto jc) { copy1(st_fill, jc); });
             advance();
-            prefetch();
             st = st_next;
+            if (--c_rem == 0)
+                if (!finish_item()) break;
         }
     }
     wait_vmcnt<0>();        // no copy may land in LDS after this workgroup has given it back
-
-    if (part == nullptr) {
-        igemm_epilogue<MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lrow, lk, 0, Nb, rpb);
-    } else {
-        // slab of this (slice, tile): [MI NI blocks][4 register quads][NTH threads][4 floats] -- every store instruction
-        // of a wave writes 1 KB contiguous
-        float* pp = part + ((long long)(slice * tiles + tile) * (MI * NI * 4) * NTH + tid) * 4;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(pp + (long long)((i * NI + j) * 4 + q) * NTH * 4) = v;
-                }
-    }
 }
 
 // Adds the S slabs of every 32x32 block in slice order (fixed: ((s0 + s1) + s2) + ...) and applies the epilogue.  A
@@ -439,7 +402,20 @@ __global__ void splitk_reduce_kernel(const IGemm p, const float* __restrict__ pa
     igemm_epilogue<1, JW>(p, acc, mt * BM + wm * WTM + i * 32, nt * BN + wn * WTN + j * 32, lane & 31, lane >> 5, 0, Nb, rpb);
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE, int PF>
+// Persistent grids: at most this many workgroups per CU's worth of LDS, times the CUs.  MAA_DMA2_PERSIST=0 launches one
+// workgroup per work item instead (A/B).
+int cu_count(const Ctx& ctx) {
+    static int n[16] = {0};
+    int& c = n[ctx.device & 15];
+    if (!c) {
+        hipDeviceProp_t prop;
+        MAA_HIP(hipGetDeviceProperties(&prop, ctx.device));
+        c = prop.multiProcessorCount;
+    }
+    return c;
+}
+
+template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE>
 void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
     constexpr int NW = WGM * WGN, NTH = 64 * NW;
     constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
@@ -451,16 +427,23 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
     const int Seff = (nchunks + cps - 1) / cps;            // slices that have at least one chunk
     MAA_CHECK(Seff == S, "split-K plan leaves an empty slice");
     MAA_CHECK(!p.geglu || NI % 2 == 0, "GEGLU needs value / gate block pairs inside a wave");
-    constexpr int PFI = PF > 0 ? (BM + BN + 64 * NW - 1) / (64 * NW) : 0;
-    constexpr size_t lds = (size_t)NS * (BM + BN) * 128 + (size_t)NW * PFI * 256;
+    constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
     static_assert(lds <= 163840, "LDS per workgroup");
-    auto kern = igemm_dma2_kernel<BM, BN, WGM, WGN, NS, PIPE, PF>;
+    auto kern = igemm_dma2_kernel<BM, BN, WGM, WGN, NS, PIPE>;
     static bool attr_set = false;
     if (!attr_set) {
         MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((long long)tiles * S)), dim3(NTH), lds, ctx.stream, p, ntiles, tiles, Nb, cps,
+    const long long items = (long long)tiles * S;
+    const char* pe = std::getenv("MAA_DMA2_PERSIST");
+    long long grid = items;
+    if (!pe || *pe != '0') {
+        const int per_cu = (int)(163840 / lds) < 32 / NW ? (int)(163840 / lds) : 32 / NW;      // LDS- and wave-limited residency
+        const long long cap = (long long)cu_count(ctx) * (per_cu < 1 ? 1 : per_cu);
+        if (grid > cap) grid = cap;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTH), lds, ctx.stream, p, ntiles, tiles, Nb, cps, (int)items,
                        S > 1 ? part : nullptr);
     if (S > 1) {
         if constexpr (NI % 2 == 0) {
@@ -488,8 +471,8 @@ int fit_slices(int nchunks, int S) {
 }
 
 // Which problems take this engine, with which tile and how many K slices: a function of the layer (K, packed N) only.
-// MAA_DMA2 = "off" | "cfg,ns,pipe,S[,kmin[,pf[,kmax]]]" overrides the policy for kmin <= K <= kmax (tuning and tests; read
-// on every launch).
+// MAA_DMA2 = "off" | "cfg,ns,pipe,S[,kmin[,kmax]]" overrides the policy for kmin <= K <= kmax (tuning and tests; read on
+// every launch).
 Dma2Plan plan_impl(const IGemm& p) {
     Dma2Plan pl;
     const int ncols = p.N * (p.geglu ? 2 : 1);
@@ -501,16 +484,15 @@ Dma2Plan plan_impl(const IGemm& p) {
     if (!env || !*env) env = std::getenv("MAA_DMA2");
     if (env && *env) {
         if (!std::strcmp(env, "off")) return pl;
-        int cfg = 0, ns = 2, pipe = 0, S = 1, kmin = 0, pf = 0, kmax = 1 << 30;
-        const int k = std::sscanf(env, "%d,%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &pf, &kmax);
+        int cfg = 0, ns = 2, pipe = 0, S = 1, kmin = 0, kmax = 1 << 30;
+        const int k = std::sscanf(env, "%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &kmax);
         if (k >= 4) {
-            if (p.K < kmin || (p.geglu && cfg >= 2)) return pl;
+            if (p.K < kmin || (p.geglu && (cfg == 2 || cfg == 3 || cfg == 4))) return pl;
             if (p.K > kmax) env = nullptr;          // outside the override's K range: default policy below
             if (env) {
                 pl.cfg = cfg;
                 pl.ns = ns;
                 pl.pipe = pipe;
-                pl.pf = pf;
                 pl.S = fit_slices(nchunks, S);
                 return pl;
             }
@@ -534,7 +516,6 @@ Dma2Plan plan_impl(const IGemm& p) {
         pl.ns = 4;
         pl.pipe = 1;
     }
-    pl.pf = 0;
     pl.S = fit_slices(nchunks, 2);
     return pl;
 }
@@ -546,17 +527,20 @@ Dma2Plan igemm_dma2_plan(const IGemm& p) { return plan_impl(p); }
 size_t igemm_dma2_workspace_floats(const IGemm& p, const Dma2Plan& pl) {
     if (pl.cfg < 0 || pl.S <= 1) return 0;
     const int ncols = p.N * (p.geglu ? 2 : 1);
-    const int BM = pl.cfg == 1 ? 256 : pl.cfg == 3 ? 64 : 128, BN = pl.cfg >= 2 ? 320 : 128;
+    static const int bm[5] = {128, 256, 128, 64, 128}, bn[5] = {128, 128, 320, 64, 64};
+    MAA_CHECK(pl.cfg >= 0 && pl.cfg < 5, "igemm_dma2: tile configuration");
+    const int BM = bm[pl.cfg], BN = bn[pl.cfg];
     const long long tiles = (long long)((p.M + BM - 1) / BM) * ((ncols + BN - 1) / BN);
     return (size_t)(tiles * pl.S * BM * BN);
 }
 
 const char* igemm_dma2_name(const Dma2Plan& pl) {
-    static const char* names[4][2] = {{"igemm_dma2_bf16x3<128x128>", "igemm_dma2_bf16x3<128x128,splitK>"},
+    static const char* names[5][2] = {{"igemm_dma2_bf16x3<128x128>", "igemm_dma2_bf16x3<128x128,splitK>"},
                                       {"igemm_dma2_bf16x3<256x128>", "igemm_dma2_bf16x3<256x128,splitK>"},
                                       {"igemm_dma2_bf16x3<128x320>", "igemm_dma2_bf16x3<128x320,splitK>"},
-                                      {"igemm_dma2_bf16x3<64x320>", "igemm_dma2_bf16x3<64x320,splitK>"}};
-    return names[pl.cfg < 0 || pl.cfg > 3 ? 0 : pl.cfg][pl.S > 1];
+                                      {"igemm_dma2_bf16x3<64x64>", "igemm_dma2_bf16x3<64x64,splitK>"},
+                                      {"igemm_dma2_bf16x3<128x64>", "igemm_dma2_bf16x3<128x64,splitK>"}};
+    return names[pl.cfg < 0 || pl.cfg > 4 ? 0 : pl.cfg][pl.S > 1];
 }
 
 // The caller has checked the split32 conditions (both operands split, single source, C % 32 == 0, K % 32 == 0, 16-byte
@@ -564,32 +548,28 @@ const char* igemm_dma2_name(const Dma2Plan& pl) {
 void launch_igemm_dma2(const Ctx& ctx, const IGemm& p, int Nb, const Dma2Plan& pl, float* part) {
     MAA_CHECK(pl.cfg >= 0, "igemm_dma2: problem not planned for this engine");
     MAA_CHECK(pl.S == 1 || part != nullptr, "igemm_dma2: split-K needs its slab workspace");
-    constexpr int D = 6;        // prefetch distance in chunks when the plan asks for L2 prefetch
-    const int key = pl.cfg * 1000 + pl.ns * 100 + pl.pipe * 10 + (pl.pf ? 1 : 0);
+    const int key = pl.cfg * 100 + pl.ns * 10 + pl.pipe;
     switch (key) {
         // 128x128 tiles, 4 waves of 64x64
-        case 200: launch_one<128, 128, 2, 2, 2, false, 0>(ctx, p, Nb, pl.S, part); break;
-        case 201: launch_one<128, 128, 2, 2, 2, false, D>(ctx, p, Nb, pl.S, part); break;
-        case 300: launch_one<128, 128, 2, 2, 3, false, 0>(ctx, p, Nb, pl.S, part); break;
-        case 301: launch_one<128, 128, 2, 2, 3, false, D>(ctx, p, Nb, pl.S, part); break;
-        case 401: launch_one<128, 128, 2, 2, 4, false, D>(ctx, p, Nb, pl.S, part); break;
-        case 310: launch_one<128, 128, 2, 2, 3, true, 0>(ctx, p, Nb, pl.S, part); break;
-        case 410: launch_one<128, 128, 2, 2, 4, true, 0>(ctx, p, Nb, pl.S, part); break;
-        case 411: launch_one<128, 128, 2, 2, 4, true, D>(ctx, p, Nb, pl.S, part); break;
-        case 510: launch_one<128, 128, 2, 2, 5, true, 0>(ctx, p, Nb, pl.S, part); break;
+        case 20: launch_one<128, 128, 2, 2, 2, false>(ctx, p, Nb, pl.S, part); break;
+        case 30: launch_one<128, 128, 2, 2, 3, false>(ctx, p, Nb, pl.S, part); break;
+        case 31: launch_one<128, 128, 2, 2, 3, true>(ctx, p, Nb, pl.S, part); break;
+        case 41: launch_one<128, 128, 2, 2, 4, true>(ctx, p, Nb, pl.S, part); break;
+        case 51: launch_one<128, 128, 2, 2, 5, true>(ctx, p, Nb, pl.S, part); break;
         // 256x128 tiles, 8 waves of 64x64
-        case 1200: launch_one<256, 128, 4, 2, 2, false, 0>(ctx, p, Nb, pl.S, part); break;
-        case 1201: launch_one<256, 128, 4, 2, 2, false, D>(ctx, p, Nb, pl.S, part); break;
-        case 1300: launch_one<256, 128, 4, 2, 3, false, 0>(ctx, p, Nb, pl.S, part); break;
-        case 1310: launch_one<256, 128, 4, 2, 3, true, 0>(ctx, p, Nb, pl.S, part); break;
-        case 1311: launch_one<256, 128, 4, 2, 3, true, D>(ctx, p, Nb, pl.S, part); break;
+        case 120: launch_one<256, 128, 4, 2, 2, false>(ctx, p, Nb, pl.S, part); break;
+        case 130: launch_one<256, 128, 4, 2, 3, false>(ctx, p, Nb, pl.S, part); break;
+        case 131: launch_one<256, 128, 4, 2, 3, true>(ctx, p, Nb, pl.S, part); break;
         // 128x320 tiles (all of N = 320 in one tile), 8 waves of 32x160
-        case 2200: launch_one<128, 320, 4, 2, 2, false, 0>(ctx, p, Nb, pl.S, part); break;
-        case 2201: launch_one<128, 320, 4, 2, 2, false, D>(ctx, p, Nb, pl.S, part); break;
-        // 64x320 tiles, 4 waves of 32x160: short-K problems of the N = 320 / 640 layers (A read once, more bytes in flight)
-        case 3200: launch_one<64, 320, 2, 2, 2, false, 0>(ctx, p, Nb, pl.S, part); break;
-        case 3300: launch_one<64, 320, 2, 2, 3, false, 0>(ctx, p, Nb, pl.S, part); break;
-        default: MAA_CHECK(false, "igemm_dma2: no such (tile, stages, pipe, prefetch) instantiation");
+        case 220: launch_one<128, 320, 4, 2, 2, false>(ctx, p, Nb, pl.S, part); break;
+        // 64x64 tiles, 4 waves of 32x32: the short-K problems, as persistent workgroups
+        case 320: launch_one<64, 64, 2, 2, 2, false>(ctx, p, Nb, pl.S, part); break;
+        case 340: launch_one<64, 64, 2, 2, 4, false>(ctx, p, Nb, pl.S, part); break;
+        case 341: launch_one<64, 64, 2, 2, 4, true>(ctx, p, Nb, pl.S, part); break;
+        // 128x64 tiles, 4 waves of 64x32
+        case 430: launch_one<128, 64, 2, 2, 3, false>(ctx, p, Nb, pl.S, part); break;
+        case 441: launch_one<128, 64, 2, 2, 4, true>(ctx, p, Nb, pl.S, part); break;
+        default: MAA_CHECK(false, "igemm_dma2: no such (tile, stages, pipe) instantiation");
     }
 }
 

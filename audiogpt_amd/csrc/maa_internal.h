@@ -155,12 +155,11 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms);   // false: n
 // bf16x3 with LDS-DMA tile copies, both operands split32 (igemm_dma.hip); called by launch_igemm_bf16
 int igemm_dma_tile(const IGemm& p, int cfg);      // tile the DMA engine runs for the generic choice `cfg`
 void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb);
-void launch_igemm_dma_lean(const Ctx& ctx, const IGemm& p, int Nb);   // experimental 64x64 variant (MAA_DMA_LEAN)
 // second LDS-DMA engine (igemm_dma2.hip): 128x128 / 256x128 tiles, 64x64 outputs per wave, split-K finished by a
 // fixed-order reduce kernel.  `takes` and the slab size depend on the layer (K, packed N) only, never on M.
 struct Dma2Plan {
-    int cfg = -1;       // -1: not taken.  0: 128x128 / 4 waves, 1: 256x128 / 8 waves, 2: 128x320 / 8 waves, 3: 64x320 / 4 waves
-    int ns = 2, pipe = 0, S = 1, pf = 0;      // LDS stages, in-wave pipelining, K slices, L2 prefetch on / off
+    int cfg = -1;       // -1: not taken.  tile / waves: 0 128x128 / 4, 1 256x128 / 8, 2 128x320 / 8, 3 64x64 / 4, 4 128x64 / 4
+    int ns = 2, pipe = 0, S = 1;      // LDS stages, in-wave pipelining, K slices
 };
 Dma2Plan igemm_dma2_plan(const IGemm& p);
 size_t igemm_dma2_workspace_floats(const IGemm& p, const Dma2Plan& pl);      // 0: no split-K for this problem

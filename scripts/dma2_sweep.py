@@ -18,22 +18,20 @@ SHAPES = [("c320-320@10x78", 16, 10, 78, 320, 320, 9), ("c640-320@10x78", 16, 10
           ("l320-960 M12480", 16, 10, 78, 320, 960, 1),
           ("l640-640 M3120", 16, 5, 39, 640, 640, 1), ("l2560-640 M3120", 16, 5, 39, 2560, 640, 1),
           ("l640-1920 M3120", 16, 5, 39, 640, 1920, 1)]
-if mode == "full":      # the long-K problems this engine is for (the short-K linears stay with the round-1 kernels)
-    SHAPES = [s for s in SHAPES if s[0] not in ("l320-320 M12480", "l640-640 M3120", "l320-960 M12480", "l640-1920 M3120")]
+
 if mode == "quick":
     SHAPES = [SHAPES[0], SHAPES[4], SHAPES[8], SHAPES[11]]
 
 CONFIGS = [("r1 engines", "off")]
-# (tile cfg, LDS stages, in-wave pipelining, L2 prefetch)
-VAR = ((0, 2, 0, 0), (0, 2, 0, 1), (0, 3, 0, 0), (0, 3, 0, 1), (0, 4, 0, 1), (0, 3, 1, 0), (0, 4, 1, 0), (0, 4, 1, 1), (0, 5, 1, 0),
-       (1, 2, 0, 0), (1, 2, 0, 1), (1, 3, 0, 0), (1, 3, 1, 0), (1, 3, 1, 1), (2, 2, 0, 0), (2, 2, 0, 1))
-for cfg, ns, pipe, pf in VAR:
-    for S in (1, 2, 3, 4):
-        CONFIGS.append(("t%d ns%d p%d f%d S%d" % (cfg, ns, pipe, pf, S), "%d,%d,%d,%d,0,%d" % (cfg, ns, pipe, S, pf)))
+# (tile cfg, LDS stages, in-wave pipelining)
+VAR = ((0, 2, 0), (0, 4, 1), (1, 3, 1), (2, 2, 0), (3, 2, 0), (3, 4, 0), (3, 4, 1), (4, 3, 0), (4, 4, 1))
+for cfg, ns, pipe in VAR:
+    for S in (1, 2, 4):
+        CONFIGS.append(("t%d ns%d p%d S%d" % (cfg, ns, pipe, S), "%d,%d,%d,%d" % (cfg, ns, pipe, S)))
 if mode == "quick":
-    CONFIGS = [c for c in CONFIGS if c[1] in ("off", "0,2,0,1,0,0", "0,2,0,2,0,0", "0,2,0,2,0,1", "0,4,1,2,0,1", "2,2,0,2,0,1")]
+    CONFIGS = [c for c in CONFIGS if c[1] in ("off", "0,4,1,2", "2,2,0,2", "3,4,0,1", "3,2,0,1", "4,3,0,1")]
 if mode == "ablate":
-    CONFIGS = [("r1 engines", "off"), ("t0 ns2 f0 S2", "0,2,0,2,0,0"), ("t0 ns2 f1 S2", "0,2,0,2,0,1"), ("t2 ns2 f1 S2", "2,2,0,2,0,1")]
+    CONFIGS = [("r1 engines", "off"), ("t0 ns4 p1 S2", "0,4,1,2"), ("t3 ns4 S1", "3,4,0,1"), ("t2 ns2 S2", "2,2,0,2")]
 
 from audiogpt_amd.backend import Context  # noqa: E402
 

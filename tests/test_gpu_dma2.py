@@ -17,11 +17,10 @@ from tests.util import check
 pytestmark = pytest.mark.gpu
 
 TOL = 2e-4
-# cfg (0: 128x128 / 4 waves, 1: 256x128 / 8 waves, 2: 128x320 / 8 waves), LDS stages, in-wave pipelining, K slices
-# [, minimum K, L2 prefetch]
-VARIANTS = ["0,2,0,1", "0,2,0,4", "0,3,0,3", "0,3,1,2", "0,4,1,5", "1,2,0,2", "1,3,0,1", "1,3,1,3",
-            "0,2,0,4,0,1", "0,3,0,2,0,1", "0,4,0,3,0,1", "0,4,1,2,0,1", "0,5,1,2", "1,2,0,3,0,1", "1,3,1,2,0,1",
-            "2,2,0,1", "2,2,0,3,0,1", "3,2,0,1", "3,3,0,2"]
+# tile cfg (0: 128x128 / 4 waves, 1: 256x128 / 8, 2: 128x320 / 8, 3: 64x64 / 4, 4: 128x64 / 4), LDS stages, in-wave
+# pipelining, K slices [, minimum K, maximum K]
+VARIANTS = ["0,2,0,1", "0,2,0,4", "0,3,0,3", "0,3,1,2", "0,4,1,5", "0,5,1,2", "1,2,0,2", "1,3,0,1", "1,3,1,3",
+            "2,2,0,1", "2,2,0,3", "3,2,0,1", "3,4,0,2", "3,4,1,1", "4,3,0,1", "4,4,1,2"]
 
 
 @pytest.fixture(scope="module")
@@ -104,14 +103,14 @@ def test_identity_asymmetric(ctx):
     K = N = 256
     a = torch.eye(K)
     w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 17.0 + torch.arange(N)[:, None] * 0.5
-    for variant in ("0,2,0,1", "0,2,0,4", "1,3,1,2", "2,2,0,2,0,1", "0,4,1,2,0,1"):
+    for variant in ("0,2,0,1", "0,2,0,4", "1,3,1,2", "2,2,0,2", "0,4,1,2", "3,4,1,1", "4,3,0,2"):
         with forced(variant):
             y = ctx.op_linear(a, w)
         check(f"dma2[{variant}]_identity", y, w.t().contiguous(), TOL)
 
 
-@pytest.mark.parametrize("variant", ["0,2,0,1", "0,3,0,1", "0,3,1,1", "0,4,1,1", "1,2,0,1", "1,3,1,1", "0,2,0,1,0,1",
-                                     "0,4,1,1,0,1", "0,5,1,1", "2,2,0,1", "2,2,0,1,0,1", "3,3,0,1"])
+@pytest.mark.parametrize("variant", ["0,2,0,1", "0,3,0,1", "0,3,1,1", "0,4,1,1", "0,5,1,1", "1,2,0,1", "1,3,1,1", "2,2,0,1",
+                                     "3,2,0,1", "3,4,0,1", "3,4,1,1", "4,3,0,1", "4,4,1,1"])
 def test_one_slice_is_bit_identical_to_the_other_engines(ctx, variant):
     """Same products in the same order per accumulator: without a K split this engine, the 64x64 LDS-DMA engine and the
     register-staged engine agree bit for bit."""
@@ -128,7 +127,7 @@ def test_one_slice_is_bit_identical_to_the_other_engines(ctx, variant):
     assert torch.equal(y, y_reg)
 
 
-@pytest.mark.parametrize("variant", ["0,2,0,4", "1,3,1,3", "2,2,0,2,0,1", "0,4,1,2,0,1", None])
+@pytest.mark.parametrize("variant", ["0,2,0,4", "1,3,1,3", "2,2,0,2", "0,4,1,2", "3,4,0,3", None])
 def test_split_k_is_deterministic_and_batch_invariant(ctx, variant):
     """Slices are added in slice order by a separate kernel and their number depends on the layer only: repeated runs
     are bit-identical, and a sample's rows do not change with the batch they are computed in (None = default policy)."""
@@ -143,3 +142,27 @@ def test_split_k_is_deterministic_and_batch_invariant(ctx, variant):
     assert torch.equal(y6, y6b)
     assert torch.equal(y6[4:5], y1)
     check(f"dma2[{variant}]_conv_640_b6", y6, F.conv2d(x, w, b, padding=1), TOL)
+
+
+@pytest.mark.parametrize("variant", ["3,4,0,1", "3,4,1,1", "3,2,0,2", "0,4,1,2", "4,3,0,1", "2,2,0,2"])
+def test_persistent_workgroups_match_one_workgroup_per_item(ctx, variant):
+    """A grid smaller than the number of (slice, tile) items: every workgroup runs several items as one stream of K
+    chunks (the next item's copies are issued before this item's epilogue).  Batch 16 of the benchmark's 10x78 level has
+    975 64x64 tiles -- several per workgroup; the result must be bit-identical to one workgroup per item."""
+    x = torch.randn(16, 320, 10, 78, generator=g(41))
+    w = torch.randn(320, 320, 3, 3, generator=g(42)) / math.sqrt(2880)
+    b = torch.randn(320, generator=g(43))
+    with forced(variant):
+        y = ctx.op_conv(x, w, b, pad=1).cpu()
+        os.environ["MAA_DMA2_PERSIST"] = "0"
+        try:
+            y1 = ctx.op_conv(x, w, b, pad=1).cpu()
+        finally:
+            os.environ.pop("MAA_DMA2_PERSIST", None)
+    assert torch.equal(y, y1)
+    check(f"dma2[{variant}]_persistent_conv_b16", y, F.conv2d(x, w, b, padding=1), TOL)
+    a = torch.randn(12480, 320, generator=g(44))
+    wl = torch.randn(960, 320, generator=g(45)) / math.sqrt(320)
+    with forced(variant):
+        z = ctx.op_linear(a, wl).cpu()
+    check(f"dma2[{variant}]_persistent_linear_12480x320x960", z, F.linear(a, wl), TOL)
