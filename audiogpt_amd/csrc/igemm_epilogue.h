@@ -34,6 +34,11 @@ __device__ __forceinline__ float fast_erff(float x) {
     return copysignf(t < 1.0f ? small : large, x);
 }
 
+// Pins a loaded value: the load is waited for HERE, once, in straight-line code.  Without it the compiler sinks the first
+// use into the per-row `if (m < M)` branches and has to wait there -- with vmcnt(0), i.e. also for every store issued by
+// the earlier rows, which turns a block's 16 stores into 16 dependent round trips.
+__device__ __forceinline__ void settle(float& x) { asm volatile("" : "+v"(x)); }
+
 // one output element in the split32 form (row pitch unchanged: every 32 columns = [32 bf16 hi | 32 bf16 lo])
 __device__ __forceinline__ void store_split1(float* row, int n, float v) {
     unsigned short* o = reinterpret_cast<unsigned short*>(row) + (n >> 5) * 64 + (n & 31);
@@ -60,19 +65,28 @@ __device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI]
                     const int cpk = n_base + j * 32 + lrow;          // packed value column
                     const int ncol = (cpk >> 6) * 32 + lrow;         // output column
                     if (cpk + 32 < Nb && ncol < p.N) {
-                        const float bv = p.bias ? p.bias[cpk] : 0.f;
-                        const float bg = p.bias ? p.bias[cpk + 32] : 0.f;
+                        float bv = p.bias ? p.bias[cpk] : 0.f;
+                        float bg = p.bias ? p.bias[cpk + 32] : 0.f;
+                        settle(bv);
+                        settle(bg);
+                        // values first (straight-line: the bias loads are waited for once), stores after -- a load result
+                        // first used inside a per-row branch makes every branch wait for all earlier stores as well
+                        float outv[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float val = acc[i][j][r] * p.alpha + bv;
+                            const float g = acc[i][j + 1][r] * p.alpha + bg;
+                            const float gl = 0.5f * g * (1.f + fast_erff(g * 0.70710678118654752440f));
+                            outv[r] = val * gl;
+                        }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                             if (m < p.M) {
-                                const float val = acc[i][j][r] * p.alpha + bv;
-                                const float g = acc[i][j + 1][r] * p.alpha + bg;
-                                const float gl = 0.5f * g * (1.f + fast_erff(g * 0.70710678118654752440f));
                                 if (p.c_split)
-                                    store_split1(cp + (long long)m * p.ldc, ncol, val * gl);
+                                    store_split1(cp + (long long)m * p.ldc, ncol, outv[r]);
                                 else
-                                    cp[(long long)m * p.ldc + ncol] = val * gl;
+                                    cp[(long long)m * p.ldc + ncol] = outv[r];
                             }
                         }
                     }
@@ -80,34 +94,80 @@ __device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI]
         }
         return;
     }
+    // Every global read of a 32x32 block (time-embedding row add, residual, accumulate target) is issued before the block's
+    // first store, so a block costs ONE memory round trip.  (Written as load-compute-store per element, the possible
+    // aliasing of `res` / `c` makes the compiler wait for each load and each store in turn: 32-48 dependent round trips
+    // per block -- 10-20 us per workgroup, which was the dominant cost of the short-K layers up to round 2.)
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+        // sample index of the block's rows for the per-sample row add: 32 consecutive rows span at most two samples when a
+        // sample has >= 32 rows (one division per block instead of one per row)
+        const int mb = m_base + i * 32;
+        const int b0 = mb / rpb;
+        const int nextb = (b0 + 1) * rpb;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = n_base + j * 32 + lrow;
             if (n < p.N) {
-                const float bias = p.bias ? p.bias[n] : 0.f;
+                float bias = p.bias ? p.bias[n] : 0.f;
+                float ra[16], rs[16], cv[16];
+                // unconditional loads from clamped rows under wave-uniform "is this term present" branches: straight-line
+                // code, all of a block's reads in flight together
+                long long mc[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    mc[r] = m < p.M ? m : p.M - 1;
+                    ra[r] = rs[r] = cv[r] = 0.f;
+                }
+                if (p.rowadd) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int bb = rpb >= 32 ? (mc[r] < nextb ? b0 : b0 + 1) : (int)(mc[r] / rpb);
+                        ra[r] = p.rowadd[(long long)bb * p.ld_rowadd + n];
+                    }
+                }
+                if (resp) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rs[r] = resp[mc[r] * p.ldr + n];
+                }
+                if (p.accumulate && !p.c_split) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cv[r] = cp[mc[r] * p.ldc + n];
+                }
+                // values first (straight-line: every read above is waited for once), then the stores
+                settle(bias);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    settle(ra[r]);
+                    settle(rs[r]);
+                    settle(cv[r]);
+                }
+                float outv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] * p.alpha + bias;
+                    if (p.rowadd) v += ra[r];
+                    if (resp) v += rs[r];
+                    if (p.act == 1) v = tanhf(v);
+                    else if (p.act == 2) v = fmaxf(v, 0.f);
+                    v *= p.out_scale;
+                    if (p.accumulate && !p.c_split) v += cv[r];
+                    outv[r] = v;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lk;
                     if (m < p.M) {
-                        float v = acc[i][j][r] * p.alpha + bias;
-                        if (p.rowadd) v += p.rowadd[(long long)(m / rpb) * p.ld_rowadd + n];
-                        if (resp) v += resp[(long long)m * p.ldr + n];
-                        if (p.act == 1) v = tanhf(v);
-                        else if (p.act == 2) v = fmaxf(v, 0.f);
-                        v *= p.out_scale;
-                        if (p.c_split) {
-                            store_split1(cp + (long long)m * p.ldc, n, v);
-                        } else {
-                            float* dst = cp + (long long)m * p.ldc + n;
-                            if (p.accumulate) v += *dst;
-                            *dst = v;
-                        }
+                        if (p.c_split)
+                            store_split1(cp + (long long)m * p.ldc, n, outv[r]);
+                        else
+                            cp[(long long)m * p.ldc + n] = outv[r];
                     }
                 }
             }
         }
+    }
 }
 
 }  // namespace maa

@@ -309,30 +309,69 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
         }
         return;
     }
+    // (all global reads of a block before its first store: one memory round trip per block, see igemm_epilogue.h)
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i) {
+        const int mb = m0 + wm * WTM + i * 32;
+        const int b0 = mb / rpb;
+        const int nextb = (b0 + 1) * rpb;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = n0 + wn * WTN + j * 32 + lrow;
             if (n < p.N) {
-                const float bias = p.bias ? p.bias[n] : 0.f;
+                float bias = p.bias ? p.bias[n] : 0.f;
+                float ra[16], rs[16], cv[16];
+                // unconditional loads from clamped rows under wave-uniform "is this term present" branches: straight-line
+                // code, all of a block's reads in flight together
+                long long mc[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (m < p.M) {
-                        float v = acc[i][j][r] * p.alpha + bias;
-                        if (p.rowadd) v += p.rowadd[(long long)(m / rpb) * p.ld_rowadd + n];
-                        if (resp) v += resp[(long long)m * p.ldr + n];
-                        if (p.act == 1) v = tanhf(v);
-                        else if (p.act == 2) v = fmaxf(v, 0.f);
-                        v *= p.out_scale;
-                        float* dst = cp + (long long)m * p.ldc + n;
-                        if (p.accumulate) v += *dst;
-                        *dst = v;
+                    const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    mc[r] = m < p.M ? m : p.M - 1;
+                    ra[r] = rs[r] = cv[r] = 0.f;
+                }
+                if (p.rowadd) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int bb = rpb >= 32 ? (mc[r] < nextb ? b0 : b0 + 1) : (int)(mc[r] / rpb);
+                        ra[r] = p.rowadd[(long long)bb * p.ld_rowadd + n];
                     }
+                }
+                if (resp) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rs[r] = resp[mc[r] * p.ldr + n];
+                }
+                if (p.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cv[r] = cp[mc[r] * p.ldc + n];
+                }
+                asm volatile("" : "+v"(bias));      // (loads waited for once, here: see settle() in igemm_epilogue.h)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    asm volatile("" : "+v"(ra[r]));
+                    asm volatile("" : "+v"(rs[r]));
+                    asm volatile("" : "+v"(cv[r]));
+                }
+                float outv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] * p.alpha + bias;
+                    if (p.rowadd) v += ra[r];
+                    if (resp) v += rs[r];
+                    if (p.act == 1) v = tanhf(v);
+                    else if (p.act == 2) v = fmaxf(v, 0.f);
+                    v *= p.out_scale;
+                    if (p.accumulate) v += cv[r];
+                    outv[r] = v;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (m < p.M) cp[(long long)m * p.ldc + n] = outv[r];
                 }
             }
         }
+    }
 }
 
 template <int BM, int BN, int WGM, int WGN>

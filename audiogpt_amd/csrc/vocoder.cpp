@@ -181,6 +181,11 @@ struct Vocoder::Impl {
     // dilated "same" conv1d on [B, L, C]
     void conv1d(Ctx& ctx, const T4& x, const ConvK& c, float leaky, const float* res, float out_scale, int accumulate,
                 T4& out) {
+        // narrow stages (C = 32 / 64): input tile staged once in LDS for all taps -- HBM-bound instead of L2-re-read-bound
+        if (x.C == out.C && !x.split && x.H == 1 && x.ld == 0 &&
+            launch_halo_conv1d(ctx, x.p, x.B, x.W, x.C, c.w, c.k, c.dil, leaky != 0.f ? leaky : 1.f, res, out_scale, accumulate,
+                               out.p))
+            return;
         ConvOpt o;
         o.KH = 1;
         o.KW = c.k;
