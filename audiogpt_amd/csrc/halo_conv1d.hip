@@ -1,4 +1,4 @@
-// Dilated "same" Conv1d for the narrow stages of the HiFi-GAN / BigVGAN MRF resblocks (C = 32 or 64 channels in and out),
+// Dilated "same" Conv1d for the narrow stages of the HiFi-GAN / BigVGAN MRF resblocks (C = 32, 64 or 128 channels in and out),
 // bf16x3 arithmetic: the input tile is staged ONCE in LDS and every tap reads it at a row offset.
 //
 // Replaces, at those widths, Conv1d(C, C, k, dilation = d, padding = (k d - d) / 2) with its preceding leaky-ReLU inside
@@ -12,7 +12,7 @@
 // output): at 8 TB/s the HBM bound is 16x (C = 32, k = 3) .. 1.1x (C = 64, k = 11) below the bf16x3 MFMA bound, i.e. the
 // layer should be HBM-bound.  Staging the tile once makes the L2->CU bytes equal to the HBM bytes.
 //
-// One workgroup (4 waves) per tile of TL = 256 output positions of one sample; persistent over tiles.
+// One workgroup (4 waves) per tile of TL = 256 (C = 32) or 128 (C = 64) output positions of one sample; persistent over tiles.
 //   * A image: rows l0 - H .. l0 + TL + H (H = d (k-1) / 2 <= 25) read as fp32 (coalesced float4 x 2 per lane), leaky-ReLU
 //     applied, split into bf16 hi / lo and written as split32 lines (ds_write_b128, slot XOR-swizzled by (row >> 1) & 7)
 //     -- rows outside [0, L) are zeros (the conv's zero padding; leaky(0) = 0)
@@ -36,10 +36,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TL = 256;            // output positions per tile
 constexpr int HMAX = 32;           // halo rows reserved on each side (needs d (k-1) / 2 <= HMAX)
-constexpr int AROWS = TL + 2 * HMAX;
-constexpr int NSB = 4;             // weight ring stages
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -67,10 +64,13 @@ struct HaloArgs {
     int tiles_per_sample, tiles;
 };
 
-template <int C>
+// TL = output positions per tile (4 waves x MI 32-row blocks); NSB = weight ring stages
+template <int C, int TL, int NSB>
 __global__ __launch_bounds__(256) void halo_conv1d_kernel(const HaloArgs a) {
+    constexpr int AROWS = TL + 2 * HMAX;
     constexpr int CB = C / 32;                 // 128-byte lines per row = 32-channel blocks
-    constexpr int NI = C / 32, MI = 2;
+    constexpr int NI = C / 32, MI = TL / 128;
+    static_assert(TL == 128 || TL == 256, "tile length");
     constexpr int A_BYTES = AROWS * CB * 128;
     constexpr int BSTAGE = C * 128;            // one weight chunk: C rows x 128 B
     constexpr int IPW = C / 32;                // LDS-DMA copies (8 rows x 128 B) per wave and chunk: C / 8 / 4 waves
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void halo_conv1d_kernel(const HaloArgs a) {
             bf16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int row = wid * 64 + i * 32 + lrow + tap * a.dil;      // image row of this lane's output position + tap
+                const int row = wid * (32 * MI) + i * 32 + lrow + tap * a.dil;      // image row of this lane's output position + tap
                 const char* line = smem + (row * CB + cb) * 128;
                 const int sw = (row >> 1) & 7;
 #pragma unroll
@@ -228,15 +228,16 @@ __global__ __launch_bounds__(256) void halo_conv1d_kernel(const HaloArgs a) {
         IGemm q = a.g;
         const int mrow0 = b * a.L + l0;
         q.M = b * a.L + min(a.L, l0 + TL);
-        igemm_epilogue<MI, NI>(q, acc, mrow0 + wid * 64, 0, lrow, lk, 0, C, 1);
+        igemm_epilogue<MI, NI>(q, acc, mrow0 + wid * (32 * MI), 0, lrow, lk, 0, C, 1);
         __builtin_amdgcn_s_barrier();              // everybody is done reading the image before the next tile overwrites it
     }
 }
 
-template <int C>
+template <int C, int TL, int NSB>
 void launch_c(const Ctx& ctx, const HaloArgs& a) {
-    constexpr size_t lds = (size_t)AROWS * (C / 32) * 128 + (size_t)NSB * C * 128;
-    auto kern = halo_conv1d_kernel<C>;
+    constexpr size_t lds = (size_t)(TL + 2 * HMAX) * (C / 32) * 128 + (size_t)NSB * C * 128;
+    static_assert(lds <= 163840, "LDS per workgroup");
+    auto kern = halo_conv1d_kernel<C, TL, NSB>;
     static bool attr_set = false;
     if (!attr_set) {
         MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -263,7 +264,8 @@ void launch_c(const Ctx& ctx, const HaloArgs& a) {
 bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, const PackedW& w, int k, int dil, float slope,
                         const float* res, float out_scale, int accumulate, float* out) {
     static const bool off = std::getenv("MAA_NO_HALO") != nullptr;
-    if (off || ctx.dtype != 1 || !(C == 32 || C == 64) || w.N != C || w.K != k * C || !w.split || !w.nk) return false;
+    static const bool no128 = std::getenv("MAA_HALO_NO128") != nullptr;       // A/B
+    if (off || ctx.dtype != 1 || !(C == 32 || C == 64 || (C == 128 && !no128)) || w.N != C || w.K != k * C || !w.split || !w.nk) return false;
     if (k < 1 || (k & 1) == 0 || dil < 1 || dil * (k - 1) / 2 > HMAX) return false;
     if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (long long)B * L * C >= (1ll << 31)) return false;
     if (ctx.ws.dry) return true;
@@ -286,14 +288,23 @@ bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, con
     a.k = k;
     a.dil = dil;
     a.slope = slope;
-    a.tiles_per_sample = (L + TL - 1) / TL;
+    // tile length: 256 positions at C = 32 (56 KB of LDS, two workgroups per CU); 128 at C = 64 (80 KB: still two per CU, so
+    // one workgroup's tile staging overlaps the other's MFMAs; 256 would be 112 KB and one per CU).  MAA_HALO_TL64=256: A/B.
+    static const int tl64 = std::getenv("MAA_HALO_TL64") ? std::atoi(std::getenv("MAA_HALO_TL64")) : 128;
+    const int TLr = C == 32 ? 256 : C == 128 ? 128 : (tl64 == 256 ? 256 : 128);
+    a.tiles_per_sample = (L + TLr - 1) / TLr;
     a.tiles = B * a.tiles_per_sample;
     const double flops = 2.0 * B * (double)L * C * (double)C * k;
-    ProfScope prof(ctx, C == 32 ? "halo_conv1d_bf16x3<32>" : "halo_conv1d_bf16x3<64>", flops, 12.0 * B * (double)L * C);
+    ProfScope prof(ctx, C == 32 ? "halo_conv1d_bf16x3<32>" : C == 64 ? "halo_conv1d_bf16x3<64>" : "halo_conv1d_bf16x3<128>", flops,
+                   12.0 * B * (double)L * C);
     if (C == 32)
-        launch_c<32>(ctx, a);
+        launch_c<32, 256, 4>(ctx, a);
+    else if (C == 128)
+        launch_c<128, 128, 3>(ctx, a);      // 96 KB image + 48 KB ring: one workgroup per CU
+    else if (TLr == 256)
+        launch_c<64, 256, 4>(ctx, a);
     else
-        launch_c<64>(ctx, a);
+        launch_c<64, 128, 4>(ctx, a);
     MAA_HIP(hipGetLastError());
     return true;
 }
