@@ -1,4 +1,4 @@
-// Dilated "same" Conv1d for the narrow stages of the HiFi-GAN / BigVGAN MRF resblocks (C = 32, 64 or 128 channels in and out),
+// Dilated "same" Conv1d for the narrow stages of the HiFi-GAN / BigVGAN MRF resblocks (C = 32 or 64 channels in and out),
 // bf16x3 arithmetic: the input tile is staged ONCE in LDS and every tap reads it at a row offset.
 //
 // Replaces, at those widths, Conv1d(C, C, k, dilation = d, padding = (k d - d) / 2) with its preceding leaky-ReLU inside
@@ -264,8 +264,9 @@ void launch_c(const Ctx& ctx, const HaloArgs& a) {
 bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, const PackedW& w, int k, int dil, float slope,
                         const float* res, float out_scale, int accumulate, float* out) {
     static const bool off = std::getenv("MAA_NO_HALO") != nullptr;
-    static const bool no128 = std::getenv("MAA_HALO_NO128") != nullptr;       // A/B
-    if (off || ctx.dtype != 1 || !(C == 32 || C == 64 || (C == 128 && !no128)) || w.N != C || w.K != k * C || !w.split || !w.nk) return false;
+    // (C = 128 was tried with a 128-position tile, one workgroup per CU: 72.3 ms vs 70.6 ms for the generic engine on the
+    //  config-3 stage -- at that width the layer is MFMA-bound and gains nothing from the staging; not kept)
+    if (off || ctx.dtype != 1 || !(C == 32 || C == 64) || w.N != C || w.K != k * C || !w.split || !w.nk) return false;
     if (k < 1 || (k & 1) == 0 || dil < 1 || dil * (k - 1) / 2 > HMAX) return false;
     if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (long long)B * L * C >= (1ll << 31)) return false;
     if (ctx.ws.dry) return true;
@@ -291,16 +292,13 @@ bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, con
     // tile length: 256 positions at C = 32 (56 KB of LDS, two workgroups per CU); 128 at C = 64 (80 KB: still two per CU, so
     // one workgroup's tile staging overlaps the other's MFMAs; 256 would be 112 KB and one per CU).  MAA_HALO_TL64=256: A/B.
     static const int tl64 = std::getenv("MAA_HALO_TL64") ? std::atoi(std::getenv("MAA_HALO_TL64")) : 128;
-    const int TLr = C == 32 ? 256 : C == 128 ? 128 : (tl64 == 256 ? 256 : 128);
+    const int TLr = C == 32 ? 256 : (tl64 == 256 ? 256 : 128);
     a.tiles_per_sample = (L + TLr - 1) / TLr;
     a.tiles = B * a.tiles_per_sample;
     const double flops = 2.0 * B * (double)L * C * (double)C * k;
-    ProfScope prof(ctx, C == 32 ? "halo_conv1d_bf16x3<32>" : C == 64 ? "halo_conv1d_bf16x3<64>" : "halo_conv1d_bf16x3<128>", flops,
-                   12.0 * B * (double)L * C);
+    ProfScope prof(ctx, C == 32 ? "halo_conv1d_bf16x3<32>" : "halo_conv1d_bf16x3<64>", flops, 12.0 * B * (double)L * C);
     if (C == 32)
         launch_c<32, 256, 4>(ctx, a);
-    else if (C == 128)
-        launch_c<128, 128, 3>(ctx, a);      // 96 KB image + 48 KB ring: one workgroup per CU
     else if (TLr == 256)
         launch_c<64, 256, 4>(ctx, a);
     else

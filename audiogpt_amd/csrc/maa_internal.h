@@ -239,7 +239,7 @@ struct PackedW {
     int split = 0;          // 1: rows of w are split32 lines (row pitch ld floats)
 };
 
-// Conv1d(C, C, k, dilation) with "same" padding for the narrow vocoder stages (C = 32 / 64 / 128), bf16x3: the input tile is
+// Conv1d(C, C, k, dilation) with "same" padding for the narrow vocoder stages (C = 32 / 64), bf16x3: the input tile is
 // staged once in LDS and every tap reads it at a row offset (halo_conv1d.hip).  false: not covered, use the implicit GEMM.
 bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, const PackedW& w, int k, int dil, float slope,
                         const float* res, float out_scale, int accumulate, float* out);
