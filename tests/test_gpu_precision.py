@@ -324,10 +324,12 @@ def test_halo_conv1d_bit_identical_to_the_implicit_gemm(tmp_path):
     import numpy as np
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for tag, env in (("halo", {}), ("igemm", {"MAA_NO_HALO": "1"})):
+    # (third run: BigVGAN's Activation1d through the per-element kernel instead of the tiled one -- same arithmetic and order)
+    for tag, env in (("halo", {}), ("igemm", {"MAA_NO_HALO": "1"}), ("snake_untiled", {"MAA_SNAKE_UNTILED": "1"})):
         out = str(tmp_path / f"v_{tag}.npz")
         e = dict(os.environ)
         e.pop("MAA_NO_HALO", None)
+        e.pop("MAA_SNAKE_UNTILED", None)
         e.update(env)
         r = subprocess.run([sys.executable, "-c", _HALO_SCRIPT.format(root=root, out=out)], env=e, capture_output=True,
                            text=True, timeout=600)
@@ -335,4 +337,5 @@ def test_halo_conv1d_bit_identical_to_the_implicit_gemm(tmp_path):
         res.append(dict(np.load(out)))
     for k in res[0]:
         assert np.isfinite(res[0][k]).all()
-        assert np.array_equal(res[0][k], res[1][k]), (k, float(np.abs(res[0][k] - res[1][k]).max()))
+        for other in res[1:]:
+            assert np.array_equal(res[0][k], other[k]), (k, float(np.abs(res[0][k] - other[k]).max()))
