@@ -65,6 +65,12 @@ class maa_diffnet_config(C.Structure):
                 ("residual_channels", C.c_int), ("dilation_cycle_length", C.c_int)]
 
 
+class maa_encoder_config(C.Structure):
+    _fields_ = [("kind", C.c_int), ("layers", C.c_int), ("width", C.c_int), ("heads", C.c_int), ("mlp_dim", C.c_int),
+                ("d_proj", C.c_int), ("vocab", C.c_int), ("max_positions", C.c_int), ("patch", C.c_int),
+                ("image", C.c_int), ("ln_eps", C.c_float)]
+
+
 class maa_plms_args(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("K_step", C.c_int), ("interval", C.c_int), ("timesteps", C.c_int),
                 ("d_cond", C.c_void_p), ("h_alphas_cumprod", C.POINTER(C.c_float)), ("use_graph", C.c_int)]
@@ -76,7 +82,7 @@ EXPORTS = [
     "maa_unet_set_context", "maa_unet_forward", "maa_ddim_update", "maa_ddim_sample", "maa_vae_create",
     "maa_vae_destroy", "maa_vae_decode", "maa_vae_encode_moments", "maa_vocoder_create", "maa_vocoder_destroy",
     "maa_vocoder_forward", "maa_vocoder_forward_f0", "maa_diffnet_create", "maa_diffnet_destroy", "maa_diffnet_forward",
-    "maa_plms_sample", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
+    "maa_plms_sample", "maa_encoder_create", "maa_encoder_destroy", "maa_encoder_text", "maa_encoder_image", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
     "maa_op_attention", "maa_op_conv_transpose1d", "maa_op_snake_aa", "maa_op_bench_conv",
 ]
 
@@ -124,6 +130,10 @@ def load():
         "maa_diffnet_destroy": [vp],
         "maa_diffnet_forward": [vp, vp, vp, vp, vp, ci, ci, vp],
         "maa_plms_sample": [vp, vp, C.POINTER(maa_plms_args), vp],
+        "maa_encoder_create": [vp, C.POINTER(maa_encoder_config), C.POINTER(maa_tensor), ci, C.POINTER(vp)],
+        "maa_encoder_destroy": [vp],
+        "maa_encoder_text": [vp, vp, vp, ci, ci, vp],
+        "maa_encoder_image": [vp, vp, vp, ci, vp],
         "maa_op_linear": [vp, vp, ci, ci, fp, fp, ci, ci, vp],
         "maa_op_conv": [vp, vp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci, ci],
         "maa_op_groupnorm": [vp, vp, ci, ci, ci, fp, fp, cf, ci, vp],

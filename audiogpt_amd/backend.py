@@ -467,3 +467,64 @@ class DiffNet:
             self.close()
         except Exception:
             pass
+
+
+class Encoder:
+    """maa_encoder handle: a conditioning tower on the device.
+
+    kind "text":  BertModel(input_ids) + CLAP Projection per token, FrozenCLAPEmbedder.encode
+                  (ldm/modules/encoders/modules.py:204-211, CLAP/clap.py:8-20)
+    kind "image": open_clip VisionTransformer + L2 normalisation, FrozenGlobalNormOpenCLIPEmbedder.forward_img
+                  (ldm/modules/encoders/modules.py:340-343)"""
+
+    def __init__(self, ctx, cfg, state_dict):
+        self.ctx, self.cfg = ctx, cfg
+        c = L.maa_encoder_config()
+        c.kind = 0 if cfg["kind"] == "text" else 1
+        c.layers, c.width, c.heads, c.mlp_dim, c.d_proj = cfg["layers"], cfg["width"], cfg["heads"], cfg["mlp_dim"], cfg["d_proj"]
+        c.vocab, c.max_positions = cfg.get("vocab", 0), cfg.get("max_positions", 0)
+        c.patch, c.image = cfg.get("patch", 0), cfg.get("image", 0)
+        c.ln_eps = cfg["ln_eps"]
+        arr, n, keep = L.tensor_list(state_dict)
+        h = C.c_void_p()
+        with ctx.lock:
+            L.check(ctx.lib.maa_encoder_create(ctx.h, C.byref(c), arr, n, C.byref(h)))
+        self.h = h
+
+    def encode_tokens(self, input_ids):
+        """input_ids [B, L] (any integer dtype) -> [B, L, d_proj]."""
+        if self.cfg["kind"] != "text":
+            raise L.MaaError("encode_tokens on an image tower")
+        ids = torch.as_tensor(input_ids)
+        if ids.dim() != 2 or ids.shape[1] > self.cfg["max_positions"]:
+            raise L.MaaError("encode_tokens: input_ids %s must be [B, L <= %d]" % (tuple(ids.shape), self.cfg["max_positions"]))
+        ids = ids.to(device=self.ctx.device, dtype=torch.int32).contiguous()
+        B, Ln = ids.shape
+        out = torch.empty(B, Ln, self.cfg["d_proj"], dtype=torch.float32, device=self.ctx.device)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_encoder_text(self.ctx.h, self.h, C.c_void_p(ids.data_ptr()), B, Ln, L.dptr(out)))
+        return out
+
+    def encode_image(self, image):
+        """image [B, 3, S, S] (preprocessed) -> [B, d_proj], rows of unit length."""
+        if self.cfg["kind"] != "image":
+            raise L.MaaError("encode_image on a text tower")
+        x = _f32(image, self.ctx.device)
+        S = self.cfg["image"]
+        if x.dim() != 4 or tuple(x.shape[1:]) != (3, S, S):
+            raise L.MaaError("encode_image: image %s must be [B, 3, %d, %d]" % (tuple(x.shape), S, S))
+        out = torch.empty(x.shape[0], self.cfg["d_proj"], dtype=torch.float32, device=self.ctx.device)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_encoder_image(self.ctx.h, self.h, L.dptr(x), x.shape[0], L.dptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.maa_encoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -96,6 +96,16 @@ BIGVGAN_16K = dict(
     HIFIGAN_16K, kind="bigvgan", activation="snakebeta", snake_logscale=True,
 )
 
+# ---------------------------------------------------------------- conditioning encoders
+# CLAP text branch: transformers' bert-base-uncased + Projection 768 -> 1024 (encoders/CLAP/config.yml, CLAP/clap.py:8-45);
+# FrozenCLAPEmbedder pads / truncates to 77 tokens (encoders/modules.py:175,204-206)
+CLAP_TEXT = dict(kind="text", layers=12, width=768, heads=12, mlp_dim=3072, d_proj=1024, vocab=30522, max_positions=512,
+                 type_vocab=2, ln_eps=1e-12, max_length=77)
+# OpenCLIP ViT-H-14 image tower (open_clip model config "ViT-H-14": width 1280, 32 layers, head width 80, mlp ratio 4,
+# patch 14, image 224, embed_dim 1024), as FrozenGlobalNormOpenCLIPEmbedder builds it (encoders/modules.py:319-321)
+OPENCLIP_VITH14_IMAGE = dict(kind="image", layers=32, width=1280, heads=16, mlp_dim=5120, d_proj=1024, patch=14, image=224,
+                             ln_eps=1e-5)
+
 
 def small(cfg, **over):
     """A reduced copy of a config for quick tests."""

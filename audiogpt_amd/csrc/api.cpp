@@ -25,6 +25,9 @@ struct maa_vocoder {
 struct maa_diffnet {
     std::unique_ptr<maa::DiffNet> m;
 };
+struct maa_encoder {
+    std::unique_ptr<maa::Encoder> m;
+};
 
 namespace {
 
@@ -329,6 +332,43 @@ int maa_plms_sample(maa_ctx* ctx, maa_diffnet* d, const maa_plms_args* args, flo
         bind(ctx);
         MAA_CHECK(d && args && d_x, "bad plms_sample arguments");
         d->m->plms_sample(ctx->c, *args, d_x);
+    });
+}
+
+// ------------------------------------------------------------------------------------------ conditioning encoders
+int maa_encoder_create(maa_ctx* ctx, const maa_encoder_config* cfg, const maa_tensor* tensors, int n_tensors,
+                       maa_encoder** out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(cfg && out && (cfg->kind == 0 || cfg->kind == 1) && cfg->layers > 0 && cfg->width > 0 && cfg->heads > 0 &&
+                      cfg->width % cfg->heads == 0 && cfg->width % 4 == 0 && cfg->mlp_dim > 0 && cfg->d_proj > 0 &&
+                      cfg->d_proj % 4 == 0 && cfg->ln_eps > 0.f,
+                  "bad encoder config");
+        if (cfg->kind == 0)
+            MAA_CHECK(cfg->vocab > 0 && cfg->max_positions > 0, "bad text encoder config");
+        else
+            MAA_CHECK(cfg->patch > 0 && cfg->image > 0 && cfg->image % cfg->patch == 0, "bad image encoder config");
+        auto sd = to_state_dict(tensors, n_tensors);
+        auto* e = new maa_encoder;
+        e->m.reset(new maa::Encoder(*cfg, sd, ctx->c.dtype));
+        *out = e;
+    });
+}
+int maa_encoder_destroy(maa_encoder* e) {
+    return guarded([&] { delete e; });
+}
+int maa_encoder_text(maa_ctx* ctx, maa_encoder* e, const int* d_ids, int B, int L, float* d_out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(e && d_ids && d_out && B > 0 && L > 0, "bad encoder_text arguments");
+        e->m->text(ctx->c, d_ids, B, L, d_out);
+    });
+}
+int maa_encoder_image(maa_ctx* ctx, maa_encoder* e, const float* d_img, int B, float* d_out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(e && d_img && d_out && B > 0, "bad encoder_image arguments");
+        e->m->image(ctx->c, d_img, B, d_out);
     });
 }
 

@@ -54,7 +54,7 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
 }
 
 void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const PackedW& w, const float* res,
-                 int ldr, float* out, int ldc, int geglu, int a_act, long long a_split_rows, int c_split) {
+                 int ldr, float* out, int ldc, int geglu, int a_act, long long a_split_rows, int c_split, int act) {
     IGemm p;
     p.a1 = a;
     p.lda1 = lda;
@@ -78,6 +78,7 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
     p.geglu = geglu;
     p.a_act = a_act;
     p.c_split = c_split;
+    p.act = act;
     p.c = out;
     p.ldc = ldc;
     launch_igemm(ctx, p);

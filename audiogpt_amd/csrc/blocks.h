@@ -44,7 +44,8 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
 // linear over rows of a [rows, K] matrix (any leading layout, row pitch lda)
 void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const PackedW& w, const float* res,
                  int ldr, float* out, int ldc, int geglu = 0, int a_act = 0, long long a_split_rows = 0,
-                 int c_split = 0);
+                 int c_split = 0, int act = 0);
+// act: output activation of the igemm epilogue (IGemm::act), applied after bias and residual
 // a_split_rows > 0: `a` holds split32 rows (row pitch lda floats);  c_split: write `out` as split32 rows
 
 // softmax(alpha * Q K^T) V for `heads` heads of width dh stored head-major inside rows of q/k/v

@@ -151,6 +151,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI]
                     if (resp) v += rs[r];
                     if (p.act == 1) v = tanhf(v);
                     else if (p.act == 2) v = fmaxf(v, 0.f);
+                    else if (p.act == 3) v = 0.5f * v * (1.f + fast_erff(v * 0.70710678118654752440f));
                     v *= p.out_scale;
                     if (p.accumulate && !p.c_split) v += cv[r];
                     outv[r] = v;

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(NT) void igemm_f32_kernel(const IGemm p, int ntiles
                     if (resp) v += rs[r];
                     if (p.act == 1) v = tanhf(v);
                     else if (p.act == 2) v = fmaxf(v, 0.f);
+                    else if (p.act == 3) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
                     v *= p.out_scale;
                     if (p.accumulate) v += cv[r];
                     outv[r] = v;

@@ -135,7 +135,7 @@ struct IGemm {
     const float* res = nullptr;      // residual, same indexing as c
     int ldr = 0;
     int geglu = 0;                   // value/gate column interleave (see pack.cpp), writes N/2 columns
-    int act = 0;                     // 0 none, 1 tanh, 2 relu
+    int act = 0;                     // 0 none, 1 tanh, 2 relu, 3 gelu (erf)
     float out_scale = 1.f;           // applied after bias/residual/act
     int accumulate = 0;              // c += value instead of c = value
     int c_split = 0;                 // write the output as split32 lines (bf16 engine only; no accumulate, Z == 1)

@@ -68,6 +68,19 @@ private:
     Impl* impl_;
 };
 
+class Encoder {
+public:
+    Encoder(const maa_encoder_config& cfg, const StateDict& sd, int precision);
+    ~Encoder();
+    void text(Ctx& ctx, const int* d_ids, int B, int L, float* d_out);
+    void image(Ctx& ctx, const float* d_img, int B, float* d_out);
+    const maa_encoder_config& config() const;
+
+private:
+    struct Impl;
+    Impl* impl_;
+};
+
 void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x);
 
 }  // namespace maa

@@ -293,15 +293,17 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
 void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, const float* gamma, const float* beta,
                       float eps, float* out, int out_split) {
     if (ctx.ws.dry) return;
-    MAA_CHECK(C <= 1024 && C % 4 == 0, "layernorm width");
+    MAA_CHECK(C <= 2048 && C % 4 == 0, "layernorm width");
     ProfScope prof(ctx, "layernorm", 0.0, 8.0 * rows * (double)C);
     dim3 grid((unsigned)((rows + 3) / 4));
     if (C <= 256)
         hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
     else if (C <= 512)
         hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
-    else
+    else if (C <= 1024)
         hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
+    else      // the ViT-H image tower's 1280-wide rows
+        hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
     MAA_HIP(hipGetLastError());
 }
 

@@ -335,6 +335,56 @@ def make_diffnet_state_dict(cfg, seed=7):
     return sd
 
 
+# ----------------------------------------------------------------------------- conditioning encoders
+def make_clap_text_state_dict(cfg, seed=11):
+    """`caption_encoder.`-relative keys of the CLAP checkpoint FrozenCLAPEmbedder loads (encoders/modules.py:179-183):
+    `base.*` = transformers BertModel (without its pooler, which the path never runs), `projection.*` = CLAP/clap.py:8-20."""
+    g, sd = _Gen(seed), {}
+    W, F, D = cfg["width"], cfg["mlp_dim"], cfg["d_proj"]
+    e = "base.embeddings."
+    sd[e + "word_embeddings.weight"] = g.normal((cfg["vocab"], W), 0.5)
+    sd[e + "position_embeddings.weight"] = g.normal((cfg["max_positions"], W), 0.3)
+    sd[e + "token_type_embeddings.weight"] = g.normal((cfg["type_vocab"], W), 0.3)
+    sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"] = g.gamma(W), g.beta(W)
+    for i in range(cfg["layers"]):
+        p = "base.encoder.layer.%d." % i
+        for n in ("query", "key", "value"):
+            sd[p + "attention.self.%s.weight" % n] = g.weight((W, W), 1.5 if n != "value" else 1.0)
+            sd[p + "attention.self.%s.bias" % n] = g.bias(W)
+        sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"] = g.weight((W, W)), g.bias(W)
+        sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"] = g.gamma(W), g.beta(W)
+        sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"] = g.weight((F, W)), g.bias(F)
+        sd[p + "output.dense.weight"], sd[p + "output.dense.bias"] = g.weight((W, F)), g.bias(W)
+        sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"] = g.gamma(W), g.beta(W)
+    sd["projection.linear1.weight"] = g.weight((D, W))
+    sd["projection.linear2.weight"] = g.weight((D, D))
+    sd["projection.layer_norm.weight"], sd["projection.layer_norm.bias"] = g.gamma(D), g.beta(D)
+    return sd
+
+
+def make_openclip_visual_state_dict(cfg, seed=12):
+    """`model.visual.`-relative keys of open_clip's VisionTransformer (what `open_clip.create_model_and_transforms`
+    returns for ViT-H-14; encoders/modules.py:321)."""
+    g, sd = _Gen(seed), {}
+    W, F, D, P = cfg["width"], cfg["mlp_dim"], cfg["d_proj"], cfg["patch"]
+    tokens = (cfg["image"] // P) ** 2 + 1
+    sd["conv1.weight"] = g.weight((W, 3, P, P))
+    sd["class_embedding"] = g.normal((W,), 0.5)
+    sd["positional_embedding"] = g.normal((tokens, W), 0.3)
+    sd["ln_pre.weight"], sd["ln_pre.bias"] = g.gamma(W), g.beta(W)
+    for i in range(cfg["layers"]):
+        p = "transformer.resblocks.%d." % i
+        sd[p + "ln_1.weight"], sd[p + "ln_1.bias"] = g.gamma(W), g.beta(W)
+        sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"] = g.weight((3 * W, W), 1.5), g.bias(3 * W)
+        sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"] = g.weight((W, W), 0.5), g.bias(W)
+        sd[p + "ln_2.weight"], sd[p + "ln_2.bias"] = g.gamma(W), g.beta(W)
+        sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"] = g.weight((F, W)), g.bias(F)
+        sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = g.weight((W, F), 0.5), g.bias(W)
+    sd["ln_post.weight"], sd["ln_post.bias"] = g.gamma(W), g.beta(W)
+    sd["proj"] = g.normal((W, D), W ** -0.5)
+    return sd
+
+
 def fold_weight_norm(sd):
     """weight_g / weight_v -> weight, as torch's remove_weight_norm: w = g * v / ||v||_(dims != 0)
     (NeuralSeq/modules/hifigan/hifigan.py:171-178; for ConvTranspose1d dim 0 is the in-channel axis)."""

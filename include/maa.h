@@ -217,6 +217,36 @@ typedef struct maa_plms_args {
 } maa_plms_args;
 int maa_plms_sample(maa_ctx* ctx, maa_diffnet* d, const maa_plms_args* args, float* d_x);
 
+/* ---- conditioning encoders (the step before the sampler: text / image -> cross-attention context) ----------
+ * kind 0: the CLAP text branch as FrozenCLAPEmbedder.encode runs it (ldm/modules/encoders/modules.py:204-211):
+ *   transformers BertModel (bert-base-uncased, built by TextEncoder, CLAP/clap.py:41-45) on input_ids alone -- no
+ *   attention mask, token type 0 -- then Projection (CLAP/clap.py:8-20) on EVERY token: [B, L] ids -> [B, L, d_proj].
+ *   tensors: `caption_encoder.`-relative keys: base.embeddings.{word,position,token_type}_embeddings.weight,
+ *   base.embeddings.LayerNorm.*, base.encoder.layer.{i}.attention.self.{query,key,value}.*,
+ *   .attention.output.{dense,LayerNorm}.*, .intermediate.dense.*, .output.{dense,LayerNorm}.*,
+ *   projection.{linear1,linear2}.weight, projection.layer_norm.*
+ * kind 1: the OpenCLIP image tower behind FrozenGlobalNormOpenCLIPEmbedder.forward_img (modules.py:340-343):
+ *   open_clip VisionTransformer (ViT-H-14: patch 14, width 1280, 32 layers, 16 heads, mlp 5120, GELU), CLS token ->
+ *   ln_post -> @ proj, then z / ||z||: [B, 3, image, image] (already preprocessed) -> [B, d_proj].
+ *   tensors: `model.visual.`-relative open_clip keys: conv1.weight, class_embedding, positional_embedding, ln_pre.*,
+ *   transformer.resblocks.{i}.{ln_1,ln_2}.*, .attn.{in_proj_weight,in_proj_bias}, .attn.out_proj.*, .mlp.{c_fc,c_proj}.*,
+ *   ln_post.*, proj ([width, d_proj]) */
+typedef struct maa_encoder_config {
+    int kind;                       /* 0 = BERT text + CLAP projection, 1 = OpenCLIP ViT image tower */
+    int layers, width, heads, mlp_dim, d_proj;
+    int vocab, max_positions;       /* kind 0 */
+    int patch, image;               /* kind 1 */
+    float ln_eps;                   /* 1e-12 (BERT) / 1e-5 (ViT) */
+} maa_encoder_config;
+typedef struct maa_encoder maa_encoder;
+int maa_encoder_create(maa_ctx* ctx, const maa_encoder_config* cfg, const maa_tensor* tensors, int n_tensors,
+                       maa_encoder** out);
+int maa_encoder_destroy(maa_encoder* e);
+/* kind 0: d_ids [B, L] int32 token ids on the device (tokenisation stays on the host) -> d_out [B, L, d_proj] */
+int maa_encoder_text(maa_ctx* ctx, maa_encoder* e, const int* d_ids, int B, int L, float* d_out);
+/* kind 1: d_img [B, 3, image, image] -> d_out [B, d_proj], rows L2-normalised */
+int maa_encoder_image(maa_ctx* ctx, maa_encoder* e, const float* d_img, int B, float* d_out);
+
 /* ---- single-operator entry points (parity tests and profiling of individual kernels) ------------ */
 /* y[M,N] = A[M,K] * W^T (+bias) with W given as torch Linear weight [N,K] on the HOST; A, y on device */
 int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w, const float* h_bias, int N,

@@ -445,6 +445,113 @@ def config3_case(name, cfg, row, B=64, T=1024, seed=2):
     print(name, "wav std", float(wav.std()), "absmax", float(wav.abs().max()))
 
 
+def _token_ids(B, L, vocab, seed):
+    """[CLS] words ... [SEP] then [PAD] to L, like the tokenizer's padding="max_length" output (ids only matter as indices)."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(torch.randint(3, L - 2, (1,), generator=g))
+        ids[b, 0] = 101
+        ids[b, 1:1 + n] = torch.randint(1000, vocab, (n,), generator=g)
+        ids[b, 1 + n] = 102
+    return ids
+
+
+def clap_text_case(name, cfg, manifest, B=2, seed=11):
+    """The reference's own chain (encoders/modules.py:208-211) on its own classes: transformers' BertModel (what
+    AutoModel.from_pretrained('bert-base-uncased') instantiates, CLAP/clap.py:44; BertConfig() defaults are that model's
+    dimensions) and the Projection class of the reference's CLAP/clap.py, loaded strict from the seeded factory."""
+    import importlib.util
+    from transformers import BertConfig, BertModel
+    pkg = "refclap"
+    stub = types.ModuleType(pkg)
+    stub.__path__ = []
+    audio = types.ModuleType(pkg + ".audio")
+    audio.get_audio_encoder = lambda name: None
+    sys.modules[pkg], sys.modules[pkg + ".audio"] = stub, audio
+    sp = importlib.util.spec_from_file_location(pkg + ".clap", os.path.join(MAA, "ldm/modules/encoders/CLAP/clap.py"))
+    clap = importlib.util.module_from_spec(sp)
+    sys.modules[pkg + ".clap"] = clap
+    sp.loader.exec_module(clap)
+    bc = BertConfig()
+    assert (bc.vocab_size, bc.hidden_size, bc.num_hidden_layers, bc.num_attention_heads, bc.intermediate_size,
+            bc.max_position_embeddings, bc.type_vocab_size, bc.layer_norm_eps, bc.hidden_act) == \
+        (cfg["vocab"], cfg["width"], cfg["layers"], cfg["heads"], cfg["mlp_dim"], cfg["max_positions"], cfg["type_vocab"],
+         cfg["ln_eps"], "gelu")
+    base = BertModel(bc, add_pooling_layer=False).eval()
+    proj = clap.Projection(cfg["width"], cfg["d_proj"]).eval()
+    sd = WT.make_clap_text_state_dict(cfg, seed=seed)
+    missing = base.load_state_dict({k[len("base."):]: v for k, v in sd.items() if k.startswith("base.")}, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("position_ids") for k in missing.missing_keys), missing
+    proj.load_state_dict({k[len("projection."):]: v for k, v in sd.items() if k.startswith("projection.")}, strict=True)
+    manifest[name] = {**{"base." + k: v for k, v in _manifest(base).items() if not k.endswith("position_ids")},
+                      **{"projection." + k: v for k, v in _manifest(proj).items()}}
+    ids = _token_ids(B, cfg["max_length"], cfg["vocab"], 31)
+    with torch.no_grad():
+        hidden = base(input_ids=ids).last_hidden_state          # modules.py:209
+        z = proj(hidden)                                        # modules.py:210
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), input_ids=ids.numpy(), hidden_row0=hidden[0].numpy(), z=z.numpy())
+    print(name, "hidden std", float(hidden.std()), "z std", float(z.std()), "absmax", float(z.abs().max()))
+
+
+def openclip_image_case(name, cfg, manifest, B=2, seed=12):
+    """open_clip is absent: the published ViT-H-14 image tower run through transformers' port of it
+    (CLIPVisionModelWithProjection, hidden_act "gelu"), with the open_clip-layout seeded weights mapped onto its keys;
+    then forward_img's normalisation (encoders/modules.py:341-343)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    W = cfg["width"]
+    vc = CLIPVisionConfig(hidden_size=W, intermediate_size=cfg["mlp_dim"], projection_dim=cfg["d_proj"],
+                          num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"], image_size=cfg["image"],
+                          patch_size=cfg["patch"], hidden_act="gelu", layer_norm_eps=cfg["ln_eps"], attention_dropout=0.0)
+    try:
+        vc._attn_implementation = "eager"
+    except Exception:
+        pass
+    model = CLIPVisionModelWithProjection(vc).eval()
+    sd = WT.make_openclip_visual_state_dict(cfg, seed=seed)
+    hf = {"vision_model.embeddings.class_embedding": sd["class_embedding"],
+          "vision_model.embeddings.patch_embedding.weight": sd["conv1.weight"],
+          "vision_model.embeddings.position_embedding.weight": sd["positional_embedding"],
+          "vision_model.pre_layrnorm.weight": sd["ln_pre.weight"], "vision_model.pre_layrnorm.bias": sd["ln_pre.bias"],
+          "vision_model.post_layernorm.weight": sd["ln_post.weight"], "vision_model.post_layernorm.bias": sd["ln_post.bias"],
+          "visual_projection.weight": sd["proj"].t().contiguous()}
+    for i in range(cfg["layers"]):
+        p, q = "transformer.resblocks.%d." % i, "vision_model.encoder.layers.%d." % i
+        wi, bi = sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"]
+        for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+            hf[q + "self_attn.%s.weight" % n] = wi[j * W:(j + 1) * W]
+            hf[q + "self_attn.%s.bias" % n] = bi[j * W:(j + 1) * W]
+        hf[q + "self_attn.out_proj.weight"], hf[q + "self_attn.out_proj.bias"] = sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"]
+        hf[q + "layer_norm1.weight"], hf[q + "layer_norm1.bias"] = sd[p + "ln_1.weight"], sd[p + "ln_1.bias"]
+        hf[q + "layer_norm2.weight"], hf[q + "layer_norm2.bias"] = sd[p + "ln_2.weight"], sd[p + "ln_2.bias"]
+        hf[q + "mlp.fc1.weight"], hf[q + "mlp.fc1.bias"] = sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"]
+        hf[q + "mlp.fc2.weight"], hf[q + "mlp.fc2.bias"] = sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"]
+    missing = model.load_state_dict(hf, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("position_ids") for k in missing.missing_keys), missing
+    manifest[name] = {k: list(v.shape) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(32)
+    image = torch.randn(B, 3, cfg["image"], cfg["image"], generator=g)           # a preprocessed (normalised) image batch
+    with torch.no_grad():
+        z = model(pixel_values=image).image_embeds
+        z = z / z.norm(dim=-1, keepdim=True)
+        z = z.unsqueeze(1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), image_seed=32, z=z.numpy())
+    print(name, "z", tuple(z.shape), "absmax", float(z.abs().max()))
+
+
+def main_encoders_only():
+    """`python tests/golden/make_golden.py encoders`: the conditioning-encoder cases."""
+    torch.set_num_threads(8)
+    _install_shims()
+    with open(os.path.join(HERE, "manifest.json")) as f:
+        manifest = json.load(f)
+    clap_text_case("clap_text_bert", C.CLAP_TEXT, manifest)
+    openclip_image_case("openclip_vith14_image", C.OPENCLIP_VITH14_IMAGE, manifest)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    print("torch", torch.__version__)
+
+
 def main_config3_only():
     """`python tests/golden/make_golden.py config3`"""
     torch.set_num_threads(8)
@@ -529,4 +636,4 @@ def main_ddim_variants_only():
 
 if __name__ == "__main__":
     {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "diffsinger": main_diffsinger_only,
-     "config2": main_config2_only, "config3": main_config3_only}.get(" ".join(sys.argv[1:]), main)()
+     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only}.get(" ".join(sys.argv[1:]), main)()

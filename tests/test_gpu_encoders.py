@@ -1,0 +1,83 @@
+"""the conditioning encoders on the device (csrc/encoders.cpp, encoders.hip) through the drop-in classes.
+
+Goldens (tests/golden/make_golden.py encoders): `clap_text_bert` = transformers' BertModel + the reference's CLAP
+Projection class run as FrozenCLAPEmbedder.encode runs them; `openclip_vith14_image` = the ViT-H-14 image tower through
+transformers' port of it + forward_img's normalisation.  Full-size towers (12 x 768 / 32 x 1280), seeded weights.
+"""
+import numpy as np
+import pytest
+import torch
+
+from audiogpt_amd import config as C
+from tests.util import check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("bf16x3", 2e-4)])
+def test_clap_text_context_matches_reference(golden, precision, tol):
+    from audiogpt_amd._lib import MaaError
+    from audiogpt_amd.ldm.encoders import FrozenCLAPEmbedder
+    g = golden("clap_text_bert")
+    enc = FrozenCLAPEmbedder(device="cuda:0", precision=precision)           # seeded weights (seed 11), as the golden
+    ids = torch.from_numpy(g["input_ids"])
+    z = enc.encode_tokens(ids)
+    assert z.shape == (2, C.CLAP_TEXT["max_length"], C.CLAP_TEXT["d_proj"]) and z.is_cuda
+    check(f"{precision}_clap_text_context_vs_reference", z, g["z"], tol)
+    # rows are independent of the batch they were encoded in (no padding mask: every row attends to its own 77 tokens)
+    z1 = enc.encode_tokens(ids[1:])
+    assert torch.equal(z1, z[1:])
+
+    class Tok:          # stands in for AutoTokenizer: returns the ids the golden was made with
+        def __call__(self, text, **kw):
+            assert kw["max_length"] == 77 and kw["padding"] == "max_length" and kw["truncation"]
+            return {"input_ids": ids[:len(text)]}
+    enc.tokenizer = Tok()
+    assert torch.equal(enc.encode(["a dog barking", "rain"]), z)
+    enc.tokenizer = None
+    with pytest.raises(MaaError):
+        enc.encode(["no tokenizer"])
+    with pytest.raises(MaaError):
+        enc.encode_tokens(torch.zeros(1, 600, dtype=torch.long))
+    enc.caption_encoder.close()
+    enc.ctx.close()
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("f32", 1e-4)])
+def test_openclip_image_embedding_matches_reference(golden, precision, tol):
+    from audiogpt_amd._lib import MaaError
+    from audiogpt_amd.ldm.encoders import FrozenGlobalNormOpenCLIPEmbedder
+    g = golden("openclip_vith14_image")
+    cfg = C.OPENCLIP_VITH14_IMAGE
+    enc = FrozenGlobalNormOpenCLIPEmbedder(device="cuda:0", precision=precision)      # seeded weights (seed 12)
+    image = torch.randn(2, 3, cfg["image"], cfg["image"], generator=torch.Generator().manual_seed(int(g["image_seed"])))
+    z = enc.forward_img(image)
+    assert z.shape == (2, 1, cfg["d_proj"]) and z.is_cuda
+    check(f"{precision}_openclip_image_embedding_vs_reference", z, g["z"], tol)
+    np.testing.assert_allclose(z.norm(dim=-1).cpu().numpy(), 1.0, atol=1e-6)
+    assert torch.equal(enc.forward_img(image[1:]), z[1:])
+    with pytest.raises(MaaError):
+        enc.forward_img(image[:, :, :100])
+    with pytest.raises(MaaError):
+        enc([""])                                   # the text tower is not built
+    enc.empty_text_embedding = z[0, 0].cpu()
+    assert enc([""]).shape == (1, 1, cfg["d_proj"])
+    enc.visual.close()
+    enc.ctx.close()
+
+
+def test_t2a_tool_with_the_device_text_encoder():
+    """The T2A tool with its cond_stage_model replaced by the device CLAP branch: ids -> context -> waveform without
+    leaving the GPU (one 4-step sample; the encoder's output feeds the sampler as the reference's would)."""
+    from audiogpt_amd.ldm.encoders import FrozenCLAPEmbedder
+    from audiogpt_amd.tools import T2A
+    enc = FrozenCLAPEmbedder(device="cuda:0")
+
+    class Tok:
+        def __call__(self, text, **kw):
+            g = torch.Generator().manual_seed(len(text[0]))
+            return {"input_ids": torch.randint(1000, 30000, (len(text), kw["max_length"]), generator=g)}
+    enc.tokenizer = Tok()
+    tool = T2A("cuda:0", cond_stage_model=enc)
+    sr, wav = tool.txt2audio("a dog barking", ddim_steps=4, n_samples=1)
+    assert sr == 16000 and np.isfinite(wav).all() and wav.shape[-1] == 624 * 256

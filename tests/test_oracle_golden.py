@@ -44,6 +44,7 @@ def test_state_dict_layout_matches_reference_manifest():
         "unet_inpaint": WT.make_unet_state_dict(C.UNET_INPAINT),
         "hifigan_16k_t2a.maa": WT.make_vocoder_state_dict(C.HIFIGAN_16K),
         "hifigan_ns128.ns": WT.make_vocoder_state_dict(C.HIFIGAN_NS_128),
+        "clap_text_bert": WT.make_clap_text_state_dict(C.CLAP_TEXT),      # transformers BertModel + reference Projection keys
     }
     vae = WT.make_vae_state_dict(C.VAE_DDCONFIG)
     cases["vae.decoder"] = WT.strip_prefix(vae, "decoder.")
@@ -237,3 +238,32 @@ def test_hifigan_config3_row_matches_reference(golden, name, cfg):
     with torch.no_grad():
         wav = O_voc.hifigan_forward(sd, cfg, mel)
     _close(wav.numpy(), g["wav"], 2e-6, name)
+
+
+def test_clap_text_encoder_matches_transformers_bert_and_reference_projection(golden):
+    """the oracle's BERT + CLAP Projection against transformers' BertModel and the reference's own
+    Projection class run as FrozenCLAPEmbedder.encode runs them (golden: make_golden.py encoders)."""
+    from oracle import encoders as O_enc
+    g = golden("clap_text_bert")
+    sd = WT.make_clap_text_state_dict(C.CLAP_TEXT, seed=11)
+    ids = torch.from_numpy(g["input_ids"])
+    with torch.no_grad():
+        h = O_enc.bert_forward(sd, C.CLAP_TEXT, ids)
+        z = O_enc.clap_projection(sd, h)
+    _close(h[0].numpy(), g["hidden_row0"], 2e-5, "bert last_hidden_state")
+    _close(z.numpy(), g["z"], 2e-5, "clap text context")
+
+
+def test_openclip_image_tower_matches_the_hf_port(golden):
+    """The ViT-H-14 image tower restated from open_clip's published architecture against transformers'
+    CLIPVisionModelWithProjection carrying the same (open_clip-layout) weights."""
+    from oracle import encoders as O_enc
+    g = golden("openclip_vith14_image")
+    cfg = C.OPENCLIP_VITH14_IMAGE
+    sd = WT.make_openclip_visual_state_dict(cfg, seed=12)
+    image = torch.randn(2, 3, cfg["image"], cfg["image"], generator=torch.Generator().manual_seed(int(g["image_seed"])))
+    with torch.no_grad():
+        z = O_enc.openclip_image_encode(sd, cfg, image)
+    assert z.shape == (2, 1, cfg["d_proj"])
+    _close(z.numpy(), g["z"], 2e-6, "openclip image embedding")     # unit vectors: entries ~ 0.03
+    _close(z.norm(dim=-1).numpy(), np.ones((2, 1)), 1e-6, "unit length")
