@@ -15,7 +15,9 @@ keyword arguments is the 0.10 API, whose defaults are restated here):
     200/3 Hz per mel, logarithmic above with step log(6.4) / 27), triangular filters between consecutive mel
     frequencies evaluated at the FFT bin centres, Slaney area normalisation 2 / (f[i+2] - f[i]).
 They are restated below from librosa's published algorithm; tests/test_host_logic.py checks them against an independent
-scipy.signal.stft framing, analytic tones and the filter bank's defining properties, not against librosa itself.
+scipy.signal.stft framing, analytic tones, the filter bank's defining properties, and against `transformers.audio_utils`
+(an independent implementation of the same two librosa routines: filter bank equal to 1e-9, |STFT| to 1e-6 relative) --
+not against librosa itself.
 `librosa.resample` (resampy "kaiser_best" in 0.9.2) is replaced by scipy.signal.resample_poly when the input is not
 already at 16 kHz -- a different (polyphase Kaiser) low-pass; at 16 kHz no resampling happens, as in the reference.
 """

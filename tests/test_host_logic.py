@@ -216,3 +216,22 @@ def test_mel_front_end_restatement():
     assert M.gen_mel_audio((sr, wav)).shape == (80, 1 + (5 * 16000 + 848 * 256) // 256)   # short input: reference's full-clip pad
     assert M.gen_mel_audio((sr, np.stack([wav, wav], 1))).shape[0] == 80                 # stereo -> mono
     assert M.gen_mel_audio((32000, np.repeat(wav, 2))).shape[0] == 80                    # resampled to 16 kHz
+
+
+def test_mel_front_end_against_the_transformers_restatement_of_librosa():
+    """librosa is absent; `transformers.audio_utils` ships its own implementation of the two librosa routines the
+    front end uses (Slaney-scale, Slaney-normalised triangular mel filters; centred Hann STFT).  Two independent
+    restatements of the same published algorithm agreeing to rounding is the strongest pin this image allows."""
+    import numpy as np
+    au = pytest.importorskip("transformers.audio_utils")
+    from audiogpt_amd import mel as M
+    fb = au.mel_filter_bank(num_frequency_bins=1 + M.N_FFT // 2, num_mel_filters=M.N_MELS, min_frequency=M.FMIN,
+                            max_frequency=M.FMAX, sampling_rate=M.SAMPLE_RATE, norm="slaney", mel_scale="slaney")
+    assert np.abs(fb.T - M.mel_filterbank()).max() < 1e-8
+    x = (np.random.RandomState(0).randn(2 * M.SAMPLE_RATE) * 0.1).astype(np.float32)
+    win = au.window_function(M.N_FFT, "hann", periodic=True)
+    for pad_mode in ("constant", "reflect"):
+        s = au.spectrogram(x, win, frame_length=M.N_FFT, hop_length=M.HOP, fft_length=M.N_FFT, power=1.0, center=True,
+                           pad_mode=pad_mode)
+        m = M.stft_magnitude(x, pad_mode=pad_mode)
+        assert s.shape == m.shape and np.abs(s - m).max() < 1e-5 * np.abs(m).max()
