@@ -480,7 +480,7 @@ class Encoder:
     def __init__(self, ctx, cfg, state_dict):
         self.ctx, self.cfg = ctx, cfg
         c = L.maa_encoder_config()
-        c.kind = 0 if cfg["kind"] == "text" else 1
+        c.kind = {"text": 0, "image": 1, "clip_text": 2}[cfg["kind"]]
         c.layers, c.width, c.heads, c.mlp_dim, c.d_proj = cfg["layers"], cfg["width"], cfg["heads"], cfg["mlp_dim"], cfg["d_proj"]
         c.vocab, c.max_positions = cfg.get("vocab", 0), cfg.get("max_positions", 0)
         c.patch, c.image = cfg.get("patch", 0), cfg.get("image", 0)
@@ -492,15 +492,16 @@ class Encoder:
         self.h = h
 
     def encode_tokens(self, input_ids):
-        """input_ids [B, L] (any integer dtype) -> [B, L, d_proj]."""
-        if self.cfg["kind"] != "text":
+        """input_ids [B, L] (any integer dtype) -> [B, L, d_proj] (kind "text") / unit-length [B, d_proj] ("clip_text")."""
+        if self.cfg["kind"] == "image":
             raise L.MaaError("encode_tokens on an image tower")
         ids = torch.as_tensor(input_ids)
         if ids.dim() != 2 or ids.shape[1] > self.cfg["max_positions"]:
             raise L.MaaError("encode_tokens: input_ids %s must be [B, L <= %d]" % (tuple(ids.shape), self.cfg["max_positions"]))
         ids = ids.to(device=self.ctx.device, dtype=torch.int32).contiguous()
         B, Ln = ids.shape
-        out = torch.empty(B, Ln, self.cfg["d_proj"], dtype=torch.float32, device=self.ctx.device)
+        shape = (B, Ln, self.cfg["d_proj"]) if self.cfg["kind"] == "text" else (B, self.cfg["d_proj"])
+        out = torch.empty(*shape, dtype=torch.float32, device=self.ctx.device)
         with self.ctx.lock:
             L.check(self.ctx.lib.maa_encoder_text(self.ctx.h, self.h, C.c_void_p(ids.data_ptr()), B, Ln, L.dptr(out)))
         return out

@@ -105,6 +105,10 @@ CLAP_TEXT = dict(kind="text", layers=12, width=768, heads=12, mlp_dim=3072, d_pr
 # patch 14, image 224, embed_dim 1024), as FrozenGlobalNormOpenCLIPEmbedder builds it (encoders/modules.py:319-321)
 OPENCLIP_VITH14_IMAGE = dict(kind="image", layers=32, width=1280, heads=16, mlp_dim=5120, d_proj=1024, patch=14, image=224,
                              ln_eps=1e-5)
+# OpenCLIP ViT-H-14 text tower (open_clip model config "ViT-H-14": context 77, vocab 49408, width 1024, 16 heads,
+# 24 layers, embed_dim 1024): FrozenGlobalNormOpenCLIPEmbedder.forward -- I2A's unconditional prompt (audio-chatgpt.py:238)
+OPENCLIP_VITH14_TEXT = dict(kind="clip_text", layers=24, width=1024, heads=16, mlp_dim=4096, d_proj=1024, vocab=49408,
+                            max_positions=77, ln_eps=1e-5, sot=49406, eot=49407)
 
 
 def small(cfg, **over):

@@ -340,11 +340,11 @@ int maa_encoder_create(maa_ctx* ctx, const maa_encoder_config* cfg, const maa_te
                        maa_encoder** out) {
     return guarded([&] {
         bind(ctx);
-        MAA_CHECK(cfg && out && (cfg->kind == 0 || cfg->kind == 1) && cfg->layers > 0 && cfg->width > 0 && cfg->heads > 0 &&
+        MAA_CHECK(cfg && out && cfg->kind >= 0 && cfg->kind <= 2 && cfg->layers > 0 && cfg->width > 0 && cfg->heads > 0 &&
                       cfg->width % cfg->heads == 0 && cfg->width % 4 == 0 && cfg->mlp_dim > 0 && cfg->d_proj > 0 &&
                       cfg->d_proj % 4 == 0 && cfg->ln_eps > 0.f,
                   "bad encoder config");
-        if (cfg->kind == 0)
+        if (cfg->kind != 1)
             MAA_CHECK(cfg->vocab > 0 && cfg->max_positions > 0, "bad text encoder config");
         else
             MAA_CHECK(cfg->patch > 0 && cfg->image > 0 && cfg->image % cfg->patch == 0, "bad image encoder config");

@@ -86,9 +86,10 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
 
 void attention_into(Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk, const float* v,
                     int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha, float* out, int ldo,
-                    int out_split) {
+                    int out_split, int causal) {
+    MAA_CHECK(!causal || Nq == Nk, "causal attention needs Nq == Nk");
     if (launch_flash_attention(ctx, q, ldq, hsq, k, ldk, hsk, v, ldv, hsv, B, heads, dh, Nq, Nk, alpha, out, ldo,
-                               out_split))
+                               out_split, causal))
         return;
     MAA_CHECK(!out_split, "split32 attention output needs the fused kernel");
     const size_t mk = ctx.ws.mark();
@@ -116,7 +117,7 @@ void attention_into(Ctx& ctx, const float* q, int ldq, int hsq, const float* k, 
     p.c = S;
     p.ldc = ldS;
     launch_igemm(ctx, p);
-    launch_softmax(ctx, S, (long long)B * heads * Nq, Nk, ldS);
+    launch_softmax(ctx, S, (long long)B * heads * Nq, Nk, ldS, causal ? Nq : 0);
     IGemm r;
     r.a1 = S;
     r.lda1 = ldS;

@@ -18,10 +18,10 @@ __global__ __launch_bounds__(NT) void bert_embed_kernel(const int* __restrict__ 
     const int l = (int)(row % L);
     const float4* w = reinterpret_cast<const float4*>(word + (long long)id * C);
     const float4* p = reinterpret_cast<const float4*>(pos + (long long)l * C);
-    const float4* t = reinterpret_cast<const float4*>(type0);
+    const float4* t = reinterpret_cast<const float4*>(type0);      // null: no token-type term (OpenCLIP's text tower)
     float4* o = reinterpret_cast<float4*>(out + row * C);
     for (int c = threadIdx.x; c < C / 4; c += NT) {
-        const float4 a = w[c], b = t[c], d = p[c];
+        const float4 a = w[c], b = t ? t[c] : make_float4(0.f, 0.f, 0.f, 0.f), d = p[c];
         o[c] = make_float4((a.x + b.x) + d.x, (a.y + b.y) + d.y, (a.z + b.z) + d.z, (a.w + b.w) + d.w);
     }
 }
@@ -47,6 +47,28 @@ __global__ __launch_bounds__(NT) void gather_rows_kernel(const float* __restrict
                                                           float* __restrict__ out) {
     const long long b = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += NT) out[b * C + c] = x[b * stride + c];
+}
+
+// out[b, :] = x[b, argmax_l ids[b, l], :]   (open_clip encode_text: the features at the end-of-text token, which has the
+// highest id; first maximum on ties, like torch.argmax)
+__global__ __launch_bounds__(NT) void gather_argmax_rows_kernel(const int* __restrict__ ids, int L, const float* __restrict__ x,
+                                                                 int C, float* __restrict__ out) {
+    __shared__ int best;
+    const long long b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int bi = 0, bv = ids[b * L];
+        for (int l = 1; l < L; ++l) {
+            const int v = ids[b * L + l];
+            if (v > bv) {
+                bv = v;
+                bi = l;
+            }
+        }
+        best = bi;
+    }
+    __syncthreads();
+    const float* src = x + (b * L + best) * C;
+    for (int c = threadIdx.x; c < C; c += NT) out[b * C + c] = src[c];
 }
 
 // z /= z.norm(dim=-1, keepdim=True): one workgroup per row
@@ -97,6 +119,13 @@ void launch_gather_rows(const Ctx& ctx, const float* x, long long stride, int B,
     if (ctx.ws.dry) return;
     ProfScope prof(ctx, "gather_rows_kernel", 0.0, 8.0 * B * (double)C);
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)B), dim3(NT), 0, ctx.stream, x, stride, C, out);
+    MAA_HIP(hipGetLastError());
+}
+
+void launch_gather_argmax_rows(const Ctx& ctx, const int* ids, int B, int L, const float* x, int C, float* out) {
+    if (ctx.ws.dry) return;
+    ProfScope prof(ctx, "gather_argmax_rows_kernel", 0.0, 8.0 * B * (double)C);
+    hipLaunchKernelGGL(gather_argmax_rows_kernel, dim3((unsigned)B), dim3(NT), 0, ctx.stream, ids, L, x, C, out);
     MAA_HIP(hipGetLastError());
 }
 

@@ -36,6 +36,7 @@ struct FlashArgs {
     int ldo;
     int out_split;                // write split32 lines (the to_out projection reads them with no conversion)
     int precise_exp;              // MAA_FLASH_PRECISE_EXP=1: libm expf instead of v_exp_f32 (A/B timing)
+    int causal;                   // query i sees keys 0 .. i only (OpenCLIP's text tower)
     long long o_bs;
     const float* zeros;
 };
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(NT) void flash_attn_kernel(const FlashArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kt * KT + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            p[r] = key < a.Nk ? sacc[r] * a.scale : -INFINITY;
+            p[r] = (key < a.Nk && (!a.causal || key <= q0 + lq)) ? sacc[r] * a.scale : -INFINITY;
             mt = fmaxf(mt, p[r]);
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
@@ -342,7 +343,7 @@ bool flash_attention_covers(const Ctx& ctx, int dh) {
 // false: shape not covered (head dim other than 32 / 40 / 64 / 80, unaligned rows) -> caller uses the GEMM path
 bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
                             const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,
-                            float* out, int ldo, int out_split) {
+                            float* out, int ldo, int out_split, int causal) {
     if (!flash_attention_covers(ctx, dh)) return false;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     if (ldq % 4 || ldk % 4 || ldv % 4 || hsq % 4 || hsk % 4 || hsv % 4 || !al16(q) || !al16(k) || !al16(v)) return false;
@@ -369,6 +370,7 @@ bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, co
     a.out_split = out_split;
     static const int precise_exp = std::getenv("MAA_FLASH_PRECISE_EXP") ? 1 : 0;
     a.precise_exp = precise_exp;
+    a.causal = causal;
     a.o_bs = (long long)Nq * ldo;
     a.zeros = ctx.zeros;
     const double flops = 4.0 * B * heads * (double)Nq * Nk * dh;

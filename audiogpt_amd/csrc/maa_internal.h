@@ -182,10 +182,10 @@ void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, 
 // fused softmax(alpha q k^T) v for the bf16 precision modes; false = shape not covered, use the GEMM path
 bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
                             const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,
-                            float* out, int ldo, int out_split = 0);
+                            float* out, int ldo, int out_split = 0, int causal = 0);
 bool flash_attention_covers(const Ctx& ctx, int dh);    // head widths launch_flash_attention takes in this mode
 // in-place row softmax over `cols` columns of a [rows, ld] matrix; columns [cols, ld) are zeroed
-void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld);
+void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld, int causal_nq = 0);
 
 // ------------------------------------------------------------------------------------------ elementwise
 void launch_timestep_embedding(const Ctx& ctx, const float* t, int B, int dim, float* out);   // [cos | sin]

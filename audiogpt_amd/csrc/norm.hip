@@ -205,12 +205,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // one wave per row; NR > 0: row cached in registers, NR == 0: three passes over memory
+// causal_nq > 0: row r belongs to query r % causal_nq, which sees keys 0 .. that index only (the rest are written as 0)
 template <int NR>
-__global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ s, long long rows, int cols, int ld) {
+__global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ s, long long rows, int cols, int ld, int causal_nq) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float* p = s + row * ld;
+    if (causal_nq > 0) {
+        const int q = (int)(row % causal_nq);
+        cols = cols < q + 1 ? cols : q + 1;
+    }
     if constexpr (NR > 0) {
         float v[NR];
         float m = -INFINITY;
@@ -307,19 +312,19 @@ void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, con
     MAA_HIP(hipGetLastError());
 }
 
-void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld) {
+void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld, int causal_nq) {
     if (ctx.ws.dry) return;
     MAA_CHECK(ld >= cols, "softmax ld");
     ProfScope prof(ctx, "softmax", 0.0, 8.0 * rows * (double)ld);
     dim3 grid((unsigned)((rows + 3) / 4));
     if (ld <= 128)
-        hipLaunchKernelGGL(softmax_kernel<2>, grid, dim3(256), 0, ctx.stream, s, rows, cols, ld);
+        hipLaunchKernelGGL(softmax_kernel<2>, grid, dim3(256), 0, ctx.stream, s, rows, cols, ld, causal_nq);
     else if (ld <= 256)
-        hipLaunchKernelGGL(softmax_kernel<4>, grid, dim3(256), 0, ctx.stream, s, rows, cols, ld);
+        hipLaunchKernelGGL(softmax_kernel<4>, grid, dim3(256), 0, ctx.stream, s, rows, cols, ld, causal_nq);
     else if (ld <= 1088)
-        hipLaunchKernelGGL(softmax_kernel<17>, grid, dim3(256), 0, ctx.stream, s, rows, cols, ld);
+        hipLaunchKernelGGL(softmax_kernel<17>, grid, dim3(256), 0, ctx.stream, s, rows, cols, ld, causal_nq);
     else
-        hipLaunchKernelGGL(softmax_kernel<0>, grid, dim3(256), 0, ctx.stream, s, rows, cols, ld);
+        hipLaunchKernelGGL(softmax_kernel<0>, grid, dim3(256), 0, ctx.stream, s, rows, cols, ld, causal_nq);
     MAA_HIP(hipGetLastError());
 }
 

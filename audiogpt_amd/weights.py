@@ -385,6 +385,26 @@ def make_openclip_visual_state_dict(cfg, seed=12):
     return sd
 
 
+def make_openclip_text_state_dict(cfg, seed=13):
+    """`model.`-relative keys of open_clip's CLIP text tower (token_embedding, positional_embedding, transformer, ln_final,
+    text_projection)."""
+    g, sd = _Gen(seed), {}
+    W, F, D = cfg["width"], cfg["mlp_dim"], cfg["d_proj"]
+    sd["token_embedding.weight"] = g.normal((cfg["vocab"], W), 0.5)
+    sd["positional_embedding"] = g.normal((cfg["max_positions"], W), 0.3)
+    for i in range(cfg["layers"]):
+        p = "transformer.resblocks.%d." % i
+        sd[p + "ln_1.weight"], sd[p + "ln_1.bias"] = g.gamma(W), g.beta(W)
+        sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"] = g.weight((3 * W, W), 1.5), g.bias(3 * W)
+        sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"] = g.weight((W, W), 0.5), g.bias(W)
+        sd[p + "ln_2.weight"], sd[p + "ln_2.bias"] = g.gamma(W), g.beta(W)
+        sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"] = g.weight((F, W)), g.bias(F)
+        sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = g.weight((W, F), 0.5), g.bias(W)
+    sd["ln_final.weight"], sd["ln_final.bias"] = g.gamma(W), g.beta(W)
+    sd["text_projection"] = g.normal((W, D), W ** -0.5)
+    return sd
+
+
 def fold_weight_norm(sd):
     """weight_g / weight_v -> weight, as torch's remove_weight_norm: w = g * v / ||v||_(dims != 0)
     (NeuralSeq/modules/hifigan/hifigan.py:171-178; for ConvTranspose1d dim 0 is the in-channel axis)."""

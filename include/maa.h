@@ -230,11 +230,17 @@ int maa_plms_sample(maa_ctx* ctx, maa_diffnet* d, const maa_plms_args* args, flo
  *   ln_post -> @ proj, then z / ||z||: [B, 3, image, image] (already preprocessed) -> [B, d_proj].
  *   tensors: `model.visual.`-relative open_clip keys: conv1.weight, class_embedding, positional_embedding, ln_pre.*,
  *   transformer.resblocks.{i}.{ln_1,ln_2}.*, .attn.{in_proj_weight,in_proj_bias}, .attn.out_proj.*, .mlp.{c_fc,c_proj}.*,
- *   ln_post.*, proj ([width, d_proj]) */
+ *   ln_post.*, proj ([width, d_proj])
+ * kind 2: the OpenCLIP text tower behind FrozenGlobalNormOpenCLIPEmbedder.forward (modules.py:334-338; the image-to-audio
+ *   tool encodes its unconditional prompt "" with it, audio-chatgpt.py:238): open_clip CLIP.encode_text (token +
+ *   positional embedding, pre-LayerNorm blocks under a causal mask, ln_final, features at the end-of-text token = argmax
+ *   of the ids, @ text_projection), then z / ||z||: [B, L] ids -> [B, d_proj].
+ *   tensors: `model.`-relative open_clip keys: token_embedding.weight, positional_embedding, transformer.resblocks.{i}.*
+ *   (as kind 1), ln_final.*, text_projection ([width, d_proj]) */
 typedef struct maa_encoder_config {
-    int kind;                       /* 0 = BERT text + CLAP projection, 1 = OpenCLIP ViT image tower */
+    int kind;                       /* 0 = BERT text + CLAP projection, 1 = OpenCLIP ViT image tower, 2 = OpenCLIP text tower */
     int layers, width, heads, mlp_dim, d_proj;
-    int vocab, max_positions;       /* kind 0 */
+    int vocab, max_positions;       /* kinds 0 and 2 */
     int patch, image;               /* kind 1 */
     float ln_eps;                   /* 1e-12 (BERT) / 1e-5 (ViT) */
 } maa_encoder_config;
@@ -242,7 +248,8 @@ typedef struct maa_encoder maa_encoder;
 int maa_encoder_create(maa_ctx* ctx, const maa_encoder_config* cfg, const maa_tensor* tensors, int n_tensors,
                        maa_encoder** out);
 int maa_encoder_destroy(maa_encoder* e);
-/* kind 0: d_ids [B, L] int32 token ids on the device (tokenisation stays on the host) -> d_out [B, L, d_proj] */
+/* d_ids [B, L] int32 token ids on the device (tokenisation stays on the host);
+ * kind 0 -> d_out [B, L, d_proj];  kind 2 -> d_out [B, d_proj], rows L2-normalised */
 int maa_encoder_text(maa_ctx* ctx, maa_encoder* e, const int* d_ids, int B, int L, float* d_out);
 /* kind 1: d_img [B, 3, image, image] -> d_out [B, d_proj], rows L2-normalised */
 int maa_encoder_image(maa_ctx* ctx, maa_encoder* e, const float* d_img, int B, float* d_out);

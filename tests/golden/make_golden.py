@@ -539,6 +539,70 @@ def openclip_image_case(name, cfg, manifest, B=2, seed=12):
     print(name, "z", tuple(z.shape), "absmax", float(z.abs().max()))
 
 
+def _clip_ids(cfg, B, seed):
+    """Rows as open_clip.tokenize writes them: <start_of_text> tokens <end_of_text> 0 ... ; row 0 is the empty prompt."""
+    g = torch.Generator().manual_seed(seed)
+    L = cfg["max_positions"]
+    ids = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = 0 if b == 0 else int(torch.randint(1, L - 2, (1,), generator=g))
+        ids[b, 0] = cfg["sot"]
+        ids[b, 1:1 + n] = torch.randint(300, cfg["sot"], (n,), generator=g)
+        ids[b, 1 + n] = cfg["eot"]
+    return ids
+
+
+def openclip_text_case(name, cfg, manifest, B=3, seed=13):
+    """open_clip is absent: CLIP.encode_text through transformers' port of it (CLIPTextModelWithProjection, hidden_act
+    "gelu": causal mask, pooled at the end-of-text token) carrying the open_clip-layout seeded weights; then forward's
+    normalisation (encoders/modules.py:337-338)."""
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    W = cfg["width"]
+    tc = CLIPTextConfig(vocab_size=cfg["vocab"], hidden_size=W, intermediate_size=cfg["mlp_dim"], projection_dim=cfg["d_proj"],
+                        num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                        max_position_embeddings=cfg["max_positions"], hidden_act="gelu", layer_norm_eps=cfg["ln_eps"],
+                        attention_dropout=0.0, bos_token_id=cfg["sot"], eos_token_id=cfg["eot"], pad_token_id=0)
+    model = CLIPTextModelWithProjection(tc).eval()
+    sd = WT.make_openclip_text_state_dict(cfg, seed=seed)
+    hf = {"text_model.embeddings.token_embedding.weight": sd["token_embedding.weight"],
+          "text_model.embeddings.position_embedding.weight": sd["positional_embedding"],
+          "text_model.final_layer_norm.weight": sd["ln_final.weight"], "text_model.final_layer_norm.bias": sd["ln_final.bias"],
+          "text_projection.weight": sd["text_projection"].t().contiguous()}
+    for i in range(cfg["layers"]):
+        p, q = "transformer.resblocks.%d." % i, "text_model.encoder.layers.%d." % i
+        wi, bi = sd[p + "attn.in_proj_weight"], sd[p + "attn.in_proj_bias"]
+        for j, n in enumerate(("q_proj", "k_proj", "v_proj")):
+            hf[q + "self_attn.%s.weight" % n] = wi[j * W:(j + 1) * W]
+            hf[q + "self_attn.%s.bias" % n] = bi[j * W:(j + 1) * W]
+        hf[q + "self_attn.out_proj.weight"], hf[q + "self_attn.out_proj.bias"] = sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"]
+        hf[q + "layer_norm1.weight"], hf[q + "layer_norm1.bias"] = sd[p + "ln_1.weight"], sd[p + "ln_1.bias"]
+        hf[q + "layer_norm2.weight"], hf[q + "layer_norm2.bias"] = sd[p + "ln_2.weight"], sd[p + "ln_2.bias"]
+        hf[q + "mlp.fc1.weight"], hf[q + "mlp.fc1.bias"] = sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"]
+        hf[q + "mlp.fc2.weight"], hf[q + "mlp.fc2.bias"] = sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"]
+    missing = model.load_state_dict(hf, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("position_ids") for k in missing.missing_keys), missing
+    manifest[name] = {k: list(v.shape) for k, v in sd.items()}
+    ids = _clip_ids(cfg, B, 33)
+    with torch.no_grad():
+        z = model(input_ids=ids).text_embeds
+        z = z / z.norm(dim=-1, keepdim=True)
+        z = z.unsqueeze(1)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), input_ids=ids.numpy(), z=z.numpy())
+    print(name, "z", tuple(z.shape), "absmax", float(z.abs().max()))
+
+
+def main_clip_text_only():
+    """`python tests/golden/make_golden.py cliptext`: the OpenCLIP text tower case only."""
+    torch.set_num_threads(8)
+    _install_shims()
+    with open(os.path.join(HERE, "manifest.json")) as f:
+        manifest = json.load(f)
+    openclip_text_case("openclip_vith14_text", C.OPENCLIP_VITH14_TEXT, manifest)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    print("torch", torch.__version__)
+
+
 def main_encoders_only():
     """`python tests/golden/make_golden.py encoders`: the conditioning-encoder cases."""
     torch.set_num_threads(8)
@@ -547,6 +611,7 @@ def main_encoders_only():
         manifest = json.load(f)
     clap_text_case("clap_text_bert", C.CLAP_TEXT, manifest)
     openclip_image_case("openclip_vith14_image", C.OPENCLIP_VITH14_IMAGE, manifest)
+    openclip_text_case("openclip_vith14_text", C.OPENCLIP_VITH14_TEXT, manifest)
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     print("torch", torch.__version__)
@@ -636,4 +701,4 @@ def main_ddim_variants_only():
 
 if __name__ == "__main__":
     {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "diffsinger": main_diffsinger_only,
-     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only}.get(" ".join(sys.argv[1:]), main)()
+     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only, "cliptext": main_clip_text_only}.get(" ".join(sys.argv[1:]), main)()

@@ -59,10 +59,36 @@ def test_openclip_image_embedding_matches_reference(golden, precision, tol):
     with pytest.raises(MaaError):
         enc.forward_img(image[:, :, :100])
     with pytest.raises(MaaError):
-        enc([""])                                   # the text tower is not built
+        enc([""])                                   # this instance was built without the text tower
     enc.empty_text_embedding = z[0, 0].cpu()
     assert enc([""]).shape == (1, 1, cfg["d_proj"])
     enc.visual.close()
+    enc.ctx.close()
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 2e-4), ("f32", 1e-4)])
+def test_openclip_text_tower_matches_reference(golden, precision, tol):
+    """Causal attention (fused kernel in bf16x3, masked softmax in exact fp32) + end-of-text pooling; the drop-in class
+    encodes the empty prompt without a tokenizer, as the image-to-audio tool needs (audio-chatgpt.py:238)."""
+    from audiogpt_amd._lib import MaaError
+    from audiogpt_amd.ldm.encoders import FrozenGlobalNormOpenCLIPEmbedder
+    g = golden("openclip_vith14_text")
+    enc = FrozenGlobalNormOpenCLIPEmbedder(device="cuda:0", precision=precision, delvisual=True, with_text=True)   # text seed 13
+    ids = torch.from_numpy(g["input_ids"])
+    z = enc.text.encode_tokens(ids)
+    assert z.shape == (3, C.OPENCLIP_VITH14_TEXT["d_proj"])
+    check(f"{precision}_openclip_text_embedding_vs_reference", z.unsqueeze(1), g["z"], tol)
+    assert torch.equal(enc.text.encode_tokens(ids[2:]), z[2:])
+    uc = enc([""])                                            # no tokenizer needed for the empty prompt
+    assert uc.shape == (1, 1, 1024) and torch.equal(uc[0, 0], z[0])
+    assert torch.equal(enc.encode(["", ""])[1], uc[0])
+    with pytest.raises(MaaError):
+        enc(["a dog"])                                        # a real prompt needs open_clip's BPE vocabulary
+    enc.tokenize = lambda text: ids[:len(text)]
+    assert torch.equal(enc(["x", "y", "z"]).squeeze(1), z)
+    with pytest.raises(MaaError):
+        enc.forward_img(torch.zeros(1, 3, 224, 224))         # delvisual=True
+    enc.text.close()
     enc.ctx.close()
 
 
@@ -81,3 +107,21 @@ def test_t2a_tool_with_the_device_text_encoder():
     tool = T2A("cuda:0", cond_stage_model=enc)
     sr, wav = tool.txt2audio("a dog barking", ddim_steps=4, n_samples=1)
     assert sr == 16000 and np.isfinite(wav).all() and wav.shape[-1] == 624 * 256
+
+
+def test_i2a_tool_with_both_device_towers():
+    """The image-to-audio tool with its cond_stage_model replaced by the device OpenCLIP towers: image -> forward_img,
+    "" -> the text tower (audio-chatgpt.py:238-243), then the sampler / VAE / BigVGAN -- one 4-step sample."""
+    from audiogpt_amd.ldm.encoders import FrozenGlobalNormOpenCLIPEmbedder
+    from audiogpt_amd.tools import I2A
+
+    def preprocess(image):          # stands in for open_clip's resize / crop / normalise transform
+        x = torch.as_tensor(np.asarray(image, dtype=np.float32)).permute(2, 0, 1)[None]
+        return torch.nn.functional.interpolate(x, size=(224, 224), mode="bilinear", align_corners=False)[0] - 0.5
+    enc = FrozenGlobalNormOpenCLIPEmbedder(device="cuda:0", with_text=True, preprocess=preprocess)
+    tool = I2A("cuda:0", cond_stage_model=enc)
+    image = np.random.RandomState(3).rand(64, 64, 3).astype(np.float32)
+    sr, wav = tool.img2audio(image, ddim_steps=4)
+    assert sr == 16000 and wav.shape == (624 * 256,) and np.isfinite(wav).all()
+    uc = tool.sampler.model.get_learned_conditioning([""])
+    assert uc.shape == (1, 1, 1024) and abs(float(uc.norm()) - 1.0) < 1e-5

@@ -267,3 +267,17 @@ def test_openclip_image_tower_matches_the_hf_port(golden):
     assert z.shape == (2, 1, cfg["d_proj"])
     _close(z.numpy(), g["z"], 2e-6, "openclip image embedding")     # unit vectors: entries ~ 0.03
     _close(z.norm(dim=-1).numpy(), np.ones((2, 1)), 1e-6, "unit length")
+
+
+def test_openclip_text_tower_matches_the_hf_port(golden):
+    """OpenCLIP's text tower (causal blocks, end-of-text pooling) against transformers' CLIPTextModelWithProjection
+    carrying the same weights; row 0 is the empty prompt the image-to-audio tool encodes."""
+    from oracle import encoders as O_enc
+    g = golden("openclip_vith14_text")
+    cfg = C.OPENCLIP_VITH14_TEXT
+    sd = WT.make_openclip_text_state_dict(cfg, seed=13)
+    ids = torch.from_numpy(g["input_ids"])
+    assert ids[0, 0] == cfg["sot"] and ids[0, 1] == cfg["eot"] and int(ids[0, 2:].abs().sum()) == 0
+    with torch.no_grad():
+        z = O_enc.openclip_text_encode(sd, cfg, ids)
+    _close(z.numpy(), g["z"], 2e-6, "openclip text embedding")
