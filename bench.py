@@ -328,7 +328,7 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
 
     from audiogpt_amd.pipeline import MakeAnAudio
-    from audiogpt_amd.shard import broadcast_conditioning, gather_waveforms, start_codes
+    from audiogpt_amd.shard import broadcast_conditioning, gather_waveforms, run_in_flight, start_codes
     # One batch of 8 prompts leaves much of the chip idle (its kernels are short and latency-bound: two independent
     # batches side by side finish in 1.57x the time of one, profiles/r2_dual_stream_probe.txt), so consecutive steps of the
     # benchmark -- independent prompt batches, each sampled exactly as BASELINE configs[1] says -- are kept `inflight` at
@@ -355,17 +355,14 @@ def main():
     cond_shape, counts = (n * world, 77, 1024), [n] * world
 
     def run_steps(k):
-        """k steps; step i runs on pipeline i % inflight while the previous inflight-1 steps are still sampling."""
-        futs, out = [], None
-        for i in range(k):
-            c, uc = broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape)   # C1: RCCL broadcast (no-op at N = 1)
-            futs.append(pool.submit(lambda p_, c_, uc_: p_.generate(x_T, c_, uc_, CFG_SCALE, S, use_graph=use_graph)[0],
-                                    pipes[i % inflight], c, uc))
-            if len(futs) >= inflight:
-                out = gather_waveforms(futs.pop(0).result(), dist, counts=counts)       # C2: gather to rank 0, in step order
-        for f in futs:
-            out = gather_waveforms(f.result(), dist, counts=counts)
-        return out
+        """k steps; step i runs on pipeline i % inflight while the previous inflight-1 steps are still sampling
+        (audiogpt_amd.shard.run_in_flight: collectives on this thread, in step order)."""
+        outs = run_in_flight(
+            k, [lambda c_, uc_, p_=p_: p_.generate(x_T, c_, uc_, CFG_SCALE, S, use_graph=use_graph)[0] for p_ in pipes],
+            lambda: broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape),       # C1: RCCL broadcast (no-op at N = 1)
+            lambda wav: gather_waveforms(wav, dist, counts=counts),                              # C2: gather to rank 0
+            pool)
+        return outs[-1] if outs else None
 
     def barrier():
         if dist is not None:

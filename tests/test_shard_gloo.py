@@ -91,3 +91,66 @@ def test_start_codes_match_reference_recipe():
     assert torch.equal(x, ref)
     parts = [shard.start_codes(55, 3, (4, 10, 78), 2, r) for r in range(2)]
     assert torch.equal(torch.cat(parts), ref)
+
+
+def _inflight_worker(rank, world, port, n_total, steps, inflight, out_path):
+    """bench.py's timed loop on CPU: `steps` prompt batches, `inflight` of them generating at once on worker threads
+    (with rank- and step-dependent delays so the threads finish out of order), collectives on the main thread."""
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    lo, hi = shard.shard_range(n_total, world, rank)
+    counts = [b - a for a, b in (shard.shard_range(n_total, world, r) for r in range(world))]
+    x_T = shard.start_codes(55, n_total, (4, 2, 3), world, rank)
+    state = {"step": 0}
+
+    def conditioning():          # a different prompt batch per step; rank 0 "ran the text encoder"
+        i = state["step"]
+        state["step"] += 1
+        if rank == 0:
+            g = torch.Generator().manual_seed(1000 + i)
+            c_all, uc_row = torch.randn(n_total, 7, 16, generator=g), torch.randn(1, 7, 16, generator=g)
+        else:
+            c_all, uc_row = None, None
+        return shard.broadcast_conditioning(c_all, uc_row, hi - lo, dev, dist, shape=(n_total, 7, 16))
+
+    def make_generator(slot):
+        calls = {"n": 0}
+
+        def generate(c, uc):
+            calls["n"] += 1
+            time.sleep(0.02 * ((slot * 3 + rank * 5 + calls["n"]) % 4))        # out-of-order completion
+            return _fake_generate(x_T, c, uc)
+        return generate
+    pool = ThreadPoolExecutor(max_workers=inflight)
+    outs = shard.run_in_flight(steps, [make_generator(s) for s in range(inflight)], conditioning,
+                               lambda wav: shard.gather_waveforms(wav, dist, counts=counts), pool)
+    assert len(outs) == steps
+    if rank == 0:
+        np.save(out_path, torch.stack(outs).numpy())
+    else:
+        assert all(o is None for o in outs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("steps,inflight", [(6, 3), (4, 3), (2, 3), (5, 1)])
+def test_batches_in_flight_keep_the_collective_order(tmp_path, steps, inflight):
+    """Every step's gathered waveforms equal the single-process result of THAT step's prompts (no cross-step mix-up, no
+    deadlock), whatever order the generating threads finish in; ragged shards (7 prompts over 2 ranks)."""
+    n_total = 7
+    out = str(tmp_path / "wav.npy")
+    mp.spawn(_inflight_worker, args=(2, _free_port(), n_total, steps, inflight, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got.shape[0] == steps
+    x_T = shard.start_codes(55, n_total, (4, 2, 3))
+    for i in range(steps):
+        g = torch.Generator().manual_seed(1000 + i)
+        c_all, uc_row = torch.randn(n_total, 7, 16, generator=g), torch.randn(1, 7, 16, generator=g)
+        c, uc = shard.broadcast_conditioning(c_all, uc_row, n_total, torch.device("cpu"), None)
+        assert np.array_equal(got[i], _fake_generate(x_T, c, uc).numpy()), i
