@@ -38,11 +38,15 @@ class MakeAnAudio:
     """UNet + VAE + vocoder replicas on one device."""
 
     def __init__(self, device="cuda:0", ldm=None, vocoder_cfg=None, unet_sd=None, vae_sd=None, vocoder_sd=None,
-                 seeds=(0, 1, 2), with_encoder=False, precision="f32"):
+                 seeds=(0, 1, 2), with_encoder=False, precision="f32", stream=None):
+        # stream: a torch.cuda.Stream this replica runs on (its library context shares it).  None: the library creates its
+        # own blocking stream, which orders against PyTorch's legacy default stream -- simple, but every default-stream op
+        # is then a barrier across ALL replicas of the device.  Several replicas side by side want one stream each.
         self.ldm = ldm or C.LDM_T2A
         self.vocoder_cfg = vocoder_cfg or C.HIFIGAN_16K
         self.precision = precision
-        self.ctx = Context(device, precision=precision)
+        self.stream = stream
+        self.ctx = Context(device, stream=stream, precision=precision)
         self.device = self.ctx.device
         unet_sd = unet_sd if unet_sd is not None else WT.make_unet_state_dict(self.ldm["unet"], seed=seeds[0])
         vae_sd = vae_sd if vae_sd is not None else WT.make_vae_state_dict(self.ldm["vae"], seed=seeds[1],
@@ -68,11 +72,26 @@ class MakeAnAudio:
     def vocode(self, spec):
         return self.vocoder(spec)[:, 0]
 
-    def generate(self, x_T, cond=None, uncond=None, scale=1.0, S=100, concat=None, use_graph=True):
-        """x_T [B,4,h,w] -> (wav [B, T*hop], spec [B,80,T], z [B,4,h,w]); all on the device."""
+    def generate_here(self, x_T, cond=None, uncond=None, scale=1.0, S=100, concat=None, use_graph=True):
+        """generate() on the CURRENT torch stream, which must be this replica's stream when it has one (the caller orders
+        inputs and outputs against other streams itself: bench.py's worker threads)."""
         z = self.sample_latents(x_T, cond, uncond, scale, S, concat, use_graph)
         spec = self.decode(z)
         return self.vocode(spec), spec, z
+
+    def generate(self, x_T, cond=None, uncond=None, scale=1.0, S=100, concat=None, use_graph=True):
+        """x_T [B,4,h,w] -> (wav [B, T*hop], spec [B,80,T], z [B,4,h,w]); all on the device.  With a private stream the
+        work is ordered after the caller's current stream on entry and the caller's stream after it on return."""
+        if self.stream is None:
+            return self.generate_here(x_T, cond, uncond, scale, S, concat, use_graph)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            out = self.generate_here(x_T, cond, uncond, scale, S, concat, use_graph)
+        cur.wait_stream(self.stream)
+        for t in out:
+            t.record_stream(cur)
+        return out
 
     def audio_seconds(self, n_clips, frames):
         return n_clips * frames * self.vocoder.hop / float(self.vocoder_cfg["sampling_rate"])

@@ -297,6 +297,9 @@ def main():
                     help="t2a: BASELINE configs[1] (the headline line, with the others under 'secondary'); hifigan64: configs[2] "
                          "alone; mixed: configs[4] on one GPU (inpaint + image-to-audio)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads of the default run")
+    ap.add_argument("--legacy-streams", action="store_true",
+                    help="replicas on library-created blocking streams (ordered against PyTorch's default stream) instead of one "
+                         "private torch stream each")
     ap.add_argument("--inflight", type=int, default=3,
                     help="prompt batches in flight per GPU: consecutive steps (independent batches of 8 prompts) run on this many "
                          "pipeline replicas / HIP streams, as a serving loop would overlap requests; 1 = strictly one after another")
@@ -335,7 +338,11 @@ def main():
     # a time on as many pipeline replicas (own HIP stream, workspace and weights), like a server overlapping requests.
     # Collectives stay on this thread, in step order.
     inflight = max(1, args.inflight)
-    pipes = [MakeAnAudio(dev, precision=args.precision) for _ in range(inflight)]
+    # each replica on its own (non-blocking) torch stream: with the library's default blocking streams every op on PyTorch's
+    # legacy default stream -- the clamp between VAE and vocoder, the collectives' bookkeeping -- is a barrier across all
+    # replicas (--legacy-streams keeps that arrangement for A/B runs)
+    pipes = [MakeAnAudio(dev, precision=args.precision, stream=None if args.legacy_streams else torch.cuda.Stream(dev))
+             for _ in range(inflight)]
     pipe = pipes[0]
     pool = ThreadPoolExecutor(max_workers=inflight)
     n = args.prompts_per_gpu
@@ -354,14 +361,41 @@ def main():
     x_T = start_codes(55, n * world, LATENT, world, rank).to(dev)
     cond_shape, counts = (n * world, 77, 1024), [n] * world
 
+    def make_generator(p_):
+        def generate(c_, uc_, ready):
+            """One prompt batch on replica p_ (worker thread): everything on the replica's own stream, after the event the
+            main thread recorded behind this batch's conditioning; returns the waveforms and the event that marks them done."""
+            done = torch.cuda.Event()
+            if p_.stream is None:
+                wav = p_.generate_here(x_T, c_, uc_, CFG_SCALE, S, use_graph=use_graph)[0]
+                done.record()
+            else:
+                with torch.cuda.stream(p_.stream):
+                    p_.stream.wait_event(ready)
+                    for t in (c_, uc_):          # allocated on the main thread's stream, read on this one: tell the allocator
+                        t.record_stream(p_.stream)
+                    wav = p_.generate_here(x_T, c_, uc_, CFG_SCALE, S, use_graph=use_graph)[0]
+                    done.record(p_.stream)
+            return wav, done
+        return generate
+
+    def conditioning():
+        c, uc = broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape)          # C1: RCCL broadcast (no-op at N = 1)
+        ready = torch.cuda.Event()
+        ready.record()
+        return c, uc, ready
+
+    def gather(res):
+        wav, done = res
+        cur = torch.cuda.current_stream()
+        cur.wait_event(done)
+        wav.record_stream(cur)
+        return gather_waveforms(wav, dist, counts=counts)                                      # C2: gather to rank 0
+
     def run_steps(k):
         """k steps; step i runs on pipeline i % inflight while the previous inflight-1 steps are still sampling
         (audiogpt_amd.shard.run_in_flight: collectives on this thread, in step order)."""
-        outs = run_in_flight(
-            k, [lambda c_, uc_, p_=p_: p_.generate(x_T, c_, uc_, CFG_SCALE, S, use_graph=use_graph)[0] for p_ in pipes],
-            lambda: broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape),       # C1: RCCL broadcast (no-op at N = 1)
-            lambda wav: gather_waveforms(wav, dist, counts=counts),                              # C2: gather to rank 0
-            pool)
+        outs = run_in_flight(k, [make_generator(p_) for p_ in pipes], conditioning, gather, pool)
         return outs[-1] if outs else None
 
     def barrier():

@@ -241,3 +241,39 @@ def test_vocoder_wrappers_match_reference(golden, precision):
     check(f"tools_{precision}_HifiGanGenerator.__call__", y, g128["wav"], 2e-4)
     r, _, _ = rel_err(y, g128["wav"])
     assert r < 2e-4
+
+
+def test_pipeline_replica_on_a_private_stream_is_bit_identical():
+    """bench.py keeps its replicas on one torch stream each (no ordering through PyTorch's legacy default stream): the
+    same batch through a replica with a private stream, called from a worker thread the way the benchmark does it, and
+    through the default arrangement."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from audiogpt_amd.pipeline import MakeAnAudio
+    n, S = 2, 4
+    x_T = torch.from_numpy(np.random.RandomState(55).randn(n, 4, 10, 78)).float().cuda()
+    g = torch.Generator().manual_seed(7)
+    c = torch.nn.functional.layer_norm(torch.randn(n, 77, 1024, generator=g), (1024,)).cuda()
+    uc = torch.nn.functional.layer_norm(torch.randn(1, 77, 1024, generator=g), (1024,)).cuda().expand(n, -1, -1).contiguous()
+    ref = MakeAnAudio("cuda:0", precision="bf16x3")
+    wav_ref, spec_ref, z_ref = ref.generate(x_T, c, uc, 1.5, S)
+    torch.cuda.synchronize()
+    rep = MakeAnAudio("cuda:0", precision="bf16x3", stream=torch.cuda.Stream())
+    wav, spec, z = rep.generate(x_T, c, uc, 1.5, S)          # ordered against the caller's stream both ways
+    assert torch.equal(z, z_ref) and torch.equal(spec, spec_ref) and torch.equal(wav, wav_ref)
+
+    def worker(ready):
+        with torch.cuda.stream(rep.stream):
+            rep.stream.wait_event(ready)
+            w = rep.generate_here(x_T, c, uc, 1.5, S)[0]
+            done = torch.cuda.Event()
+            done.record(rep.stream)
+        return w, done
+    ready = torch.cuda.Event()
+    ready.record()
+    with ThreadPoolExecutor(max_workers=1) as pool:
+        w, done = pool.submit(worker, ready).result()
+    torch.cuda.current_stream().wait_event(done)
+    assert torch.equal(w, wav_ref)
+    ref.close()
+    rep.close()
