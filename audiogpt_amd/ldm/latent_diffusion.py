@@ -89,7 +89,7 @@ class _FirstStage(object):
 
 class LatentDiffusionAudio(object):
     def __init__(self, ldm_config=None, device="cuda:0", state_dict=None, seeds=(0, 1), cond_stage_model=None,
-                 precision=None):
+                 precision=None, tokenizer=None, preprocess=None):
         self.cfg = ldm_config or C.LDM_T2A
         self.conditioning_key = self.cfg["conditioning_key"]
         self.num_timesteps = self.cfg["timesteps"]
@@ -104,6 +104,10 @@ class LatentDiffusionAudio(object):
                                                 device=self.device)
         self.scale_factor = float(self.cfg.get("scale_factor", 1.0))
         self.unet = self.vae = None
+        # conditioning encoder: the caller's; else the device towers when the checkpoint carries their weights
+        # (`cond_stage_model.*`, ldm/encoders.py); else a seeded stand-in with the encoders' output statistics
+        self._own_cond_stage = cond_stage_model is None
+        self._tokenizer, self._preprocess = tokenizer, preprocess
         self.cond_stage_model = cond_stage_model or SyntheticEmbedder(
             tokens=77 if self.cfg["unet"]["variant"] == "t2a" else 1, device=self.device)
         self.first_stage_model = _FirstStage(self, self.cfg["vae"]["embed_dim"])
@@ -131,6 +135,14 @@ class LatentDiffusionAudio(object):
         self.vae = VAE(self.ctx, self.cfg["vae"], vsd)
         if "scale_factor" in sd:
             self.scale_factor = float(sd["scale_factor"])
+        csd = WT.strip_prefix(sd, "cond_stage_model.")
+        if csd and self._own_cond_stage and self.cfg["conditioning_key"] == "crossattn":
+            from . import encoders as E          # (imports this module's Context users: keep it local)
+            if any(k.startswith("caption_encoder.") for k in csd):          # FrozenCLAPEmbedder (T2A, txt2audio-cfg.yaml)
+                self.cond_stage_model = E.FrozenCLAPEmbedder(state_dict=csd, tokenizer=self._tokenizer, ctx=self.ctx)
+            elif any(k.startswith("model.visual.") for k in csd):           # FrozenGlobalNormOpenCLIPEmbedder (I2A)
+                self.cond_stage_model = E.FrozenGlobalNormOpenCLIPEmbedder(state_dict=csd, preprocess=self._preprocess,
+                                                                           ctx=self.ctx)
         return [], []
 
     def to(self, device):

@@ -7,8 +7,11 @@ sampler / model / vocoder objects are the HIP-backed ones.  Reference quirks are
 (SURVEY.md section 0.8): `inference()` ignores its seed/scale/ddim_steps/n_samples arguments and calls
 `txt2audio` with the defaults; `Inpaint.inpaint` builds a seeded start_code and does not pass it.
 
-Outside the hot path and therefore pluggable rather than re-implemented:
-  * the conditioning encoders (`model.cond_stage_model`): see ldm/latent_diffusion.py
+Pluggable:
+  * the conditioning encoders (`model.cond_stage_model`): `cond_stage_model=` takes any object with the reference's
+    `encode` / `forward_img` / `preprocess`; when the checkpoint carries `cond_stage_model.*` weights the device towers of
+    ldm/encoders.py are built from them (`tokenizer=` / `preprocess=` supply the host-side halves); otherwise a seeded
+    stand-in with the encoders' output statistics (ldm/latent_diffusion.SyntheticEmbedder)
   * CLAP best-of-n re-ranking (`select_best_audio`, audio-chatgpt.py:185-199): pass `scorer=`; without one the
     first sample is returned
   * wav / image file I/O uses scipy + a minimal PNG/colormap path only if PIL / soundfile are absent
@@ -39,16 +42,16 @@ def _write_wav(path, wav, sr):
 
 class T2A:
     def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, cond_stage_model=None, scorer=None,
-                 precision=None):
+                 precision=None, tokenizer=None):
         print("Initializing Make-An-Audio to %s" % device)
         self.device = device
-        self.sampler = self._initialize_model(C.LDM_T2A, ckpt_state_dict, device, cond_stage_model, precision)
+        self.sampler = self._initialize_model(C.LDM_T2A, ckpt_state_dict, device, cond_stage_model, precision, tokenizer)
         self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=self.sampler.model.ctx)
         self.scorer = scorer
 
-    def _initialize_model(self, config, ckpt, device, cond_stage_model=None, precision=None):
+    def _initialize_model(self, config, ckpt, device, cond_stage_model=None, precision=None, tokenizer=None):
         model = LatentDiffusionAudio(config, device=device, state_dict=ckpt, cond_stage_model=cond_stage_model,
-                                     precision=precision)
+                                     precision=precision, tokenizer=tokenizer)
         return DDIMSampler(model)
 
     def txt2audio(self, text, seed=55, scale=1.5, ddim_steps=100, n_samples=3, W=624, H=80):
@@ -86,11 +89,13 @@ class T2A:
 
 
 class I2A:
-    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, cond_stage_model=None, precision=None):
+    def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, cond_stage_model=None, precision=None,
+                 preprocess=None):
         print("Initializing Make-An-Audio-Image to %s" % device)
         self.device = device
         model = LatentDiffusionAudio(C.LDM_I2A, device=device, state_dict=ckpt_state_dict,
-                                     cond_stage_model=cond_stage_model, seeds=(4, 1), precision=precision)
+                                     cond_stage_model=cond_stage_model, seeds=(4, 1), precision=precision,
+                                     preprocess=preprocess)
         self.sampler = DDIMSampler(model)
         self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=model.ctx)
 

@@ -125,3 +125,38 @@ def test_i2a_tool_with_both_device_towers():
     assert sr == 16000 and wav.shape == (624 * 256,) and np.isfinite(wav).all()
     uc = tool.sampler.model.get_learned_conditioning([""])
     assert uc.shape == (1, 1, 1024) and abs(float(uc.norm()) - 1.0) < 1e-5
+
+
+def test_tools_build_the_device_towers_from_a_full_checkpoint():
+    """A checkpoint in the reference layout that carries `cond_stage_model.*` (as Make-An-Audio's do): the tools build
+    the device encoders from it instead of the synthetic stand-in, on the model's own context."""
+    from audiogpt_amd import weights as WT
+    from audiogpt_amd.ldm.encoders import FrozenCLAPEmbedder, FrozenGlobalNormOpenCLIPEmbedder
+    from audiogpt_amd.tools import I2A, T2A
+
+    def ckpt(ldm, useed, cond):
+        sd = {"model.diffusion_model." + k: v for k, v in WT.make_unet_state_dict(ldm["unet"], seed=useed).items()}
+        sd.update({"first_stage_model." + k: v for k, v in WT.make_vae_state_dict(ldm["vae"], seed=1).items()})
+        sd.update({"cond_stage_model." + k: v for k, v in cond.items()})
+        return sd
+    clap = {"caption_encoder." + k: v for k, v in WT.make_clap_text_state_dict(C.CLAP_TEXT, seed=11).items()}
+    ids = torch.randint(1000, 30000, (1, 77), generator=torch.Generator().manual_seed(5))
+    t2a = T2A("cuda:0", ckpt_state_dict=ckpt(C.LDM_T2A, 0, clap), tokenizer=lambda text, **kw: {"input_ids": ids.expand(len(text), -1)})
+    enc = t2a.sampler.model.cond_stage_model
+    assert isinstance(enc, FrozenCLAPEmbedder) and enc.ctx is t2a.sampler.model.ctx
+    c = t2a.sampler.model.get_learned_conditioning(["a dog barking"])
+    assert c.shape == (1, 77, 1024) and torch.equal(c, enc.encode_tokens(ids))
+    sr, wav = t2a.txt2audio("a dog barking", ddim_steps=4, n_samples=1)
+    assert np.isfinite(wav).all()
+
+    oc = {"model.visual." + k: v for k, v in WT.make_openclip_visual_state_dict(C.OPENCLIP_VITH14_IMAGE, seed=12).items()}
+    oc.update({"model." + k: v for k, v in WT.make_openclip_text_state_dict(C.OPENCLIP_VITH14_TEXT, seed=13).items()})
+    oc["model.logit_scale"] = torch.tensor(4.6)
+    i2a = I2A("cuda:0", ckpt_state_dict=ckpt(C.LDM_I2A, 4, oc),
+              preprocess=lambda im: torch.as_tensor(np.asarray(im, dtype=np.float32)).permute(2, 0, 1))
+    enc = i2a.sampler.model.cond_stage_model
+    assert isinstance(enc, FrozenGlobalNormOpenCLIPEmbedder) and enc.text is not None and enc.visual is not None
+    uc = i2a.sampler.model.get_learned_conditioning([""])
+    assert uc.shape == (1, 1, 1024)
+    sr, wav = i2a.img2audio(np.random.RandomState(3).rand(224, 224, 3).astype(np.float32), ddim_steps=4)
+    assert np.isfinite(wav).all()
