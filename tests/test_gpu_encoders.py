@@ -92,41 +92,6 @@ def test_openclip_text_tower_matches_reference(golden, precision, tol):
     enc.ctx.close()
 
 
-def test_t2a_tool_with_the_device_text_encoder():
-    """The T2A tool with its cond_stage_model replaced by the device CLAP branch: ids -> context -> waveform without
-    leaving the GPU (one 4-step sample; the encoder's output feeds the sampler as the reference's would)."""
-    from audiogpt_amd.ldm.encoders import FrozenCLAPEmbedder
-    from audiogpt_amd.tools import T2A
-    enc = FrozenCLAPEmbedder(device="cuda:0")
-
-    class Tok:
-        def __call__(self, text, **kw):
-            g = torch.Generator().manual_seed(len(text[0]))
-            return {"input_ids": torch.randint(1000, 30000, (len(text), kw["max_length"]), generator=g)}
-    enc.tokenizer = Tok()
-    tool = T2A("cuda:0", cond_stage_model=enc)
-    sr, wav = tool.txt2audio("a dog barking", ddim_steps=4, n_samples=1)
-    assert sr == 16000 and np.isfinite(wav).all() and wav.shape[-1] == 624 * 256
-
-
-def test_i2a_tool_with_both_device_towers():
-    """The image-to-audio tool with its cond_stage_model replaced by the device OpenCLIP towers: image -> forward_img,
-    "" -> the text tower (audio-chatgpt.py:238-243), then the sampler / VAE / BigVGAN -- one 4-step sample."""
-    from audiogpt_amd.ldm.encoders import FrozenGlobalNormOpenCLIPEmbedder
-    from audiogpt_amd.tools import I2A
-
-    def preprocess(image):          # stands in for open_clip's resize / crop / normalise transform
-        x = torch.as_tensor(np.asarray(image, dtype=np.float32)).permute(2, 0, 1)[None]
-        return torch.nn.functional.interpolate(x, size=(224, 224), mode="bilinear", align_corners=False)[0] - 0.5
-    enc = FrozenGlobalNormOpenCLIPEmbedder(device="cuda:0", with_text=True, preprocess=preprocess)
-    tool = I2A("cuda:0", cond_stage_model=enc)
-    image = np.random.RandomState(3).rand(64, 64, 3).astype(np.float32)
-    sr, wav = tool.img2audio(image, ddim_steps=4)
-    assert sr == 16000 and wav.shape == (624 * 256,) and np.isfinite(wav).all()
-    uc = tool.sampler.model.get_learned_conditioning([""])
-    assert uc.shape == (1, 1, 1024) and abs(float(uc.norm()) - 1.0) < 1e-5
-
-
 def test_tools_build_the_device_towers_from_a_full_checkpoint():
     """A checkpoint in the reference layout that carries `cond_stage_model.*` (as Make-An-Audio's do): the tools build
     the device encoders from it instead of the synthetic stand-in, on the model's own context."""
