@@ -109,6 +109,11 @@ OPENCLIP_VITH14_IMAGE = dict(kind="image", layers=32, width=1280, heads=16, mlp_
 # 24 layers, embed_dim 1024): FrozenGlobalNormOpenCLIPEmbedder.forward -- I2A's unconditional prompt (audio-chatgpt.py:238)
 OPENCLIP_VITH14_TEXT = dict(kind="clip_text", layers=24, width=1024, heads=16, mlp_dim=4096, d_proj=1024, vocab=49408,
                             max_positions=77, ln_eps=1e-5, sot=49406, eot=49407)
+# CLAP audio branch of the best-of-n scorer (wav_evaluation/models/CLAPWrapper.py, CLAP/config.yml): Cnn14 on a 64-bin
+# log-mel of 5 s at 44.1 kHz (window 1024, hop 320 -> 690 frames), 2048-d embedding -> Projection -> 1024.  Oracle
+# groundwork for the rest of SURVEY 8f / N4 only (no device implementation yet).
+CLAP_AUDIO_CNN14 = dict(mel_bins=64, channels=(64, 128, 256, 512, 1024, 2048), out_emb=2048, d_proj=1024, classes_num=527,
+                        sample_rate=44100, window_size=1024, hop_size=320, fmin=50, fmax=14000, frames=690)
 
 
 def small(cfg, **over):

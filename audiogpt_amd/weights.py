@@ -405,6 +405,33 @@ def make_openclip_text_state_dict(cfg, seed=13):
     return sd
 
 
+def make_clap_audio_state_dict(cfg, seed=14):
+    """`audio_encoder.`-relative keys of the CLAP checkpoint's audio branch (CLAP/clap.py:22-39, CLAP/audio.py:113-141):
+    `base.*` = Cnn14 without its spectrogram / log-mel extractors' frozen buffers, `projection.*`."""
+    g, sd = _Gen(seed), {}
+
+    def bn(p, n):
+        sd[p + ".weight"], sd[p + ".bias"] = g.gamma(n), g.beta(n)
+        sd[p + ".running_mean"], sd[p + ".running_var"] = g.normal((n,), 0.2), 1.0 + g.normal((n,), 0.1).abs()
+        sd[p + ".num_batches_tracked"] = torch.tensor(100)
+    bn("base.bn0", cfg["mel_bins"])
+    cin = 1
+    for i, c in enumerate(cfg["channels"]):
+        p = "base.conv_block%d." % (i + 1)
+        sd[p + "conv1.weight"] = g.weight((c, cin, 3, 3), 1.4)
+        sd[p + "conv2.weight"] = g.weight((c, c, 3, 3), 1.4)
+        bn(p + "bn1", c)
+        bn(p + "bn2", c)
+        cin = c
+    E, D = cfg["out_emb"], cfg["d_proj"]
+    sd["base.fc1.weight"], sd["base.fc1.bias"] = g.weight((E, cin)), g.bias(E)
+    sd["base.fc_audioset.weight"], sd["base.fc_audioset.bias"] = g.weight((cfg["classes_num"], E)), g.bias(cfg["classes_num"])
+    sd["projection.linear1.weight"] = g.weight((D, E))
+    sd["projection.linear2.weight"] = g.weight((D, D))
+    sd["projection.layer_norm.weight"], sd["projection.layer_norm.bias"] = g.gamma(D), g.beta(D)
+    return sd
+
+
 def fold_weight_norm(sd):
     """weight_g / weight_v -> weight, as torch's remove_weight_norm: w = g * v / ||v||_(dims != 0)
     (NeuralSeq/modules/hifigan/hifigan.py:171-178; for ConvTranspose1d dim 0 is the in-channel axis)."""

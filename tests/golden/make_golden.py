@@ -603,6 +603,61 @@ def main_clip_text_only():
     print("torch", torch.__version__)
 
 
+def clap_audio_case(name, cfg, manifest, B=2, seed=14):
+    """The reference's own Cnn14 / Projection classes (CLAP/audio.py, CLAP/clap.py) from the log-mel on: torchlibrosa is
+    absent, so its two extractor classes are stubbed while the module is built and the forward is entered after them
+    (audio.py:150-176 replayed on the reference module's own submodules)."""
+    import importlib.util
+    tl = types.ModuleType("torchlibrosa")
+    st = types.ModuleType("torchlibrosa.stft")
+    st.Spectrogram = st.LogmelFilterBank = lambda *a, **k: torch.nn.Identity()
+    tl.stft = st
+    sys.modules.setdefault("torchlibrosa", tl)
+    sys.modules.setdefault("torchlibrosa.stft", st)
+    pkg = "refclap2"
+    stub = types.ModuleType(pkg)
+    stub.__path__ = []
+    sys.modules[pkg] = stub
+    mods = {}
+    for m in ("audio", "clap"):
+        sp = importlib.util.spec_from_file_location(pkg + "." + m, os.path.join(MAA, "ldm/modules/encoders/CLAP/%s.py" % m))
+        mods[m] = importlib.util.module_from_spec(sp)
+        sys.modules[pkg + "." + m] = mods[m]
+        sp.loader.exec_module(mods[m])
+    enc = mods["clap"].AudioEncoder("Cnn14", cfg["out_emb"], cfg["d_proj"], cfg["sample_rate"], cfg["window_size"],
+                                    cfg["hop_size"], cfg["mel_bins"], cfg["fmin"], cfg["fmax"], cfg["classes_num"]).eval()
+    sd = WT.make_clap_audio_state_dict(cfg, seed=seed)
+    enc.load_state_dict(sd, strict=True)
+    manifest[name] = _manifest(enc)
+    g = torch.Generator().manual_seed(34)
+    logmel = torch.randn(B, 1, cfg["frames"], cfg["mel_bins"], generator=g) * 12.0 - 30.0      # dB-like values
+    base = enc.base
+    with torch.no_grad():
+        x = base.bn0(logmel.transpose(1, 3)).transpose(1, 3)
+        for i, blk in enumerate((base.conv_block1, base.conv_block2, base.conv_block3, base.conv_block4, base.conv_block5,
+                                 base.conv_block6)):
+            x = blk(x, pool_size=(2, 2) if i < 5 else (1, 1), pool_type="avg")
+        x = torch.mean(x, dim=3)
+        x = torch.max(x, dim=2)[0] + torch.mean(x, dim=2)
+        emb = torch.relu(base.fc1(x))
+        z = enc.projection(emb)
+        z = z / torch.norm(z, dim=-1, keepdim=True)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), logmel_seed=34, embedding=emb.numpy(), z=z.numpy())
+    print(name, "embedding", tuple(emb.shape), "absmax", float(emb.abs().max()), "z absmax", float(z.abs().max()))
+
+
+def main_clap_audio_only():
+    """`python tests/golden/make_golden.py clapaudio`: the CLAP audio-branch case (groundwork, SURVEY 8f / N4 scorer)."""
+    torch.set_num_threads(8)
+    _install_shims()
+    with open(os.path.join(HERE, "manifest.json")) as f:
+        manifest = json.load(f)
+    clap_audio_case("clap_audio_cnn14", C.CLAP_AUDIO_CNN14, manifest)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    print("torch", torch.__version__)
+
+
 def main_encoders_only():
     """`python tests/golden/make_golden.py encoders`: the conditioning-encoder cases."""
     torch.set_num_threads(8)
@@ -701,4 +756,4 @@ def main_ddim_variants_only():
 
 if __name__ == "__main__":
     {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "diffsinger": main_diffsinger_only,
-     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only, "cliptext": main_clip_text_only}.get(" ".join(sys.argv[1:]), main)()
+     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only, "cliptext": main_clip_text_only, "clapaudio": main_clap_audio_only}.get(" ".join(sys.argv[1:]), main)()

@@ -45,6 +45,7 @@ def test_state_dict_layout_matches_reference_manifest():
         "hifigan_16k_t2a.maa": WT.make_vocoder_state_dict(C.HIFIGAN_16K),
         "hifigan_ns128.ns": WT.make_vocoder_state_dict(C.HIFIGAN_NS_128),
         "clap_text_bert": WT.make_clap_text_state_dict(C.CLAP_TEXT),      # transformers BertModel + reference Projection keys
+        "clap_audio_cnn14": WT.make_clap_audio_state_dict(C.CLAP_AUDIO_CNN14),     # reference AudioEncoder keys
     }
     vae = WT.make_vae_state_dict(C.VAE_DDCONFIG)
     cases["vae.decoder"] = WT.strip_prefix(vae, "decoder.")
@@ -281,3 +282,21 @@ def test_openclip_text_tower_matches_the_hf_port(golden):
     with torch.no_grad():
         z = O_enc.openclip_text_encode(sd, cfg, ids)
     _close(z.numpy(), g["z"], 2e-6, "openclip text embedding")
+
+
+def test_clap_audio_branch_matches_reference(golden):
+    """Groundwork for the best-of-n scorer: the oracle's Cnn14 + Projection from the log-mel on against
+    the reference's own AudioEncoder classes (CLAP/audio.py, CLAP/clap.py), strict state_dict."""
+    from oracle import clap_audio as O_ca
+    g = golden("clap_audio_cnn14")
+    cfg = C.CLAP_AUDIO_CNN14
+    sd = WT.make_clap_audio_state_dict(cfg, seed=14)
+    gen = torch.Generator().manual_seed(int(g["logmel_seed"]))
+    logmel = torch.randn(2, 1, cfg["frames"], cfg["mel_bins"], generator=gen) * 12.0 - 30.0
+    with torch.no_grad():
+        emb = O_ca.cnn14_embedding(sd, cfg, logmel)
+        z = O_ca.clap_audio_embed(sd, cfg, logmel)
+    _close(emb.numpy(), g["embedding"], 2e-4, "cnn14 embedding (values up to 50)")
+    _close(z.numpy(), g["z"], 2e-6, "clap audio embedding")
+    s = O_ca.similarity(z, z)
+    _close(np.diag(s.numpy()), np.ones(2), 1e-5, "self similarity")
