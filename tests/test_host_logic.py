@@ -235,3 +235,27 @@ def test_mel_front_end_against_the_transformers_restatement_of_librosa():
                            pad_mode=pad_mode)
         m = M.stft_magnitude(x, pad_mode=pad_mode)
         assert s.shape == m.shape and np.abs(s - m).max() < 1e-5 * np.abs(m).max()
+
+
+def test_product_tree_never_touches_the_oracle_or_the_reference_tree():
+    """The oracle is test infrastructure: nothing under audiogpt_amd/ (or include/) may import or name it, and nothing
+    that runs on the GPU box (product, bench.py, __graft_entry__.py, tests other than the golden generator) may read
+    the reference tree."""
+    import re
+    REF = "/root/" + "reference"          # (spelled in two pieces: this file is scanned too)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    product = []
+    for base, _, files in os.walk(os.path.join(root, "audiogpt_amd")):
+        if "_build" in base or "__pycache__" in base:
+            continue
+        product += [os.path.join(base, f) for f in files if f.endswith((".py", ".cpp", ".hip", ".h"))]
+    assert len(product) > 30
+    imp = re.compile(r"^\s*(from|import)\s+oracle\b|[\"']oracle[/\"']", re.M)
+    for path in product:
+        text = open(path, encoding="utf-8").read()
+        assert not imp.search(text), path + " refers to the oracle"
+        assert REF not in text, path + " names the reference tree"
+    runtime = [os.path.join(root, f) for f in ("bench.py", "__graft_entry__.py")]
+    runtime += [os.path.join(root, "tests", f) for f in os.listdir(os.path.join(root, "tests")) if f.endswith(".py")]
+    for path in runtime:
+        assert REF not in open(path, encoding="utf-8").read(), path + " would need the reference tree at run time"
