@@ -71,6 +71,16 @@ class maa_encoder_config(C.Structure):
                 ("image", C.c_int), ("ln_eps", C.c_float)]
 
 
+class maa_clap_audio_config(C.Structure):
+    _fields_ = [("mel_bins", C.c_int), ("n_blocks", C.c_int), ("channels", C.c_int * 8), ("out_emb", C.c_int),
+                ("d_proj", C.c_int), ("bn_eps", C.c_float)]
+
+
+class maa_spectral_config(C.Structure):
+    _fields_ = [("n_fft", C.c_int), ("hop", C.c_int), ("n_freq", C.c_int), ("n_mels", C.c_int), ("pad_mode", C.c_int),
+                ("power", C.c_int), ("log_kind", C.c_int), ("amin", C.c_float), ("ref", C.c_float), ("out_layout", C.c_int)]
+
+
 class maa_plms_args(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("K_step", C.c_int), ("interval", C.c_int), ("timesteps", C.c_int),
                 ("d_cond", C.c_void_p), ("h_alphas_cumprod", C.POINTER(C.c_float)), ("use_graph", C.c_int)]
@@ -82,7 +92,10 @@ EXPORTS = [
     "maa_unet_set_context", "maa_unet_forward", "maa_ddim_update", "maa_ddim_sample", "maa_vae_create",
     "maa_vae_destroy", "maa_vae_decode", "maa_vae_encode_moments", "maa_vocoder_create", "maa_vocoder_destroy",
     "maa_vocoder_forward", "maa_vocoder_forward_f0", "maa_diffnet_create", "maa_diffnet_destroy", "maa_diffnet_forward",
-    "maa_plms_sample", "maa_encoder_create", "maa_encoder_destroy", "maa_encoder_text", "maa_encoder_image", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
+    "maa_plms_sample", "maa_encoder_create", "maa_encoder_destroy", "maa_encoder_text", "maa_encoder_image",
+    "maa_encoder_text_cls", "maa_clap_audio_create", "maa_clap_audio_destroy", "maa_clap_audio_embed", "maa_clap_similarity",
+    "maa_spectral_create", "maa_spectral_destroy", "maa_spectral_forward", "maa_resampler_create", "maa_resampler_destroy",
+    "maa_resampler_forward", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
     "maa_op_attention", "maa_op_conv_transpose1d", "maa_op_snake_aa", "maa_op_bench_conv",
 ]
 
@@ -134,6 +147,17 @@ def load():
         "maa_encoder_destroy": [vp],
         "maa_encoder_text": [vp, vp, vp, ci, ci, vp],
         "maa_encoder_image": [vp, vp, vp, ci, vp],
+        "maa_encoder_text_cls": [vp, vp, vp, ci, ci, vp],
+        "maa_clap_audio_create": [vp, C.POINTER(maa_clap_audio_config), C.POINTER(maa_tensor), ci, C.POINTER(vp)],
+        "maa_clap_audio_destroy": [vp],
+        "maa_clap_audio_embed": [vp, vp, vp, ci, ci, vp, vp],
+        "maa_clap_similarity": [vp, vp, vp, ci, ci, ci, cf, vp],
+        "maa_spectral_create": [vp, C.POINTER(maa_spectral_config), fp, fp, C.POINTER(vp)],
+        "maa_spectral_destroy": [vp],
+        "maa_spectral_forward": [vp, vp, vp, ci, ci, vp],
+        "maa_resampler_create": [vp, ci, ci, ci, ci, fp, C.POINTER(vp)],
+        "maa_resampler_destroy": [vp],
+        "maa_resampler_forward": [vp, vp, vp, ci, ci, vp],
         "maa_op_linear": [vp, vp, ci, ci, fp, fp, ci, ci, vp],
         "maa_op_conv": [vp, vp, ci, ci, ci, ci, fp, fp, ci, ci, ci, ci, ci, ci, ci, cf, vp, ci, ci],
         "maa_op_groupnorm": [vp, vp, ci, ci, ci, fp, fp, cf, ci, vp],

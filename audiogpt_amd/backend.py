@@ -506,6 +506,21 @@ class Encoder:
             L.check(self.ctx.lib.maa_encoder_text(self.ctx.h, self.h, C.c_void_p(ids.data_ptr()), B, Ln, L.dptr(out)))
         return out
 
+    def encode_cls(self, input_ids):
+        """The scorer's text side (wav_evaluation/models/clap.py:49-53 + CLAPWrapper.py:177-182): unpadded input_ids
+        [B, L] -> Projection of the [CLS] row, unit length, [B, d_proj]."""
+        if self.cfg["kind"] != "text":
+            raise L.MaaError("encode_cls is the CLAP (BERT) tower's")
+        ids = torch.as_tensor(input_ids)
+        if ids.dim() != 2 or ids.shape[1] > self.cfg["max_positions"]:
+            raise L.MaaError("encode_cls: input_ids %s must be [B, L <= %d]" % (tuple(ids.shape), self.cfg["max_positions"]))
+        ids = ids.to(device=self.ctx.device, dtype=torch.int32).contiguous()
+        out = torch.empty(ids.shape[0], self.cfg["d_proj"], dtype=torch.float32, device=self.ctx.device)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_encoder_text_cls(self.ctx.h, self.h, C.c_void_p(ids.data_ptr()), ids.shape[0],
+                                                      ids.shape[1], L.dptr(out)))
+        return out
+
     def encode_image(self, image):
         """image [B, 3, S, S] (preprocessed) -> [B, d_proj], rows of unit length."""
         if self.cfg["kind"] != "image":
@@ -522,6 +537,150 @@ class Encoder:
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.maa_encoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ClapAudio:
+    """maa_clap_audio handle: Cnn14 from the log-mel on + Projection, unit-length rows (the audio side of the CLAP
+    best-of-n scorer: wav_evaluation/models/audio.py:150-176, clap.py:8-39, CLAPWrapper.py:184-189)."""
+
+    def __init__(self, ctx, cfg, state_dict):
+        self.ctx, self.cfg = ctx, cfg
+        c = L.maa_clap_audio_config()
+        c.mel_bins, c.out_emb, c.d_proj, c.bn_eps = cfg["mel_bins"], cfg["out_emb"], cfg["d_proj"], cfg.get("bn_eps", 1e-5)
+        c.n_blocks = _fill(c.channels, cfg["channels"])
+        arr, n, keep = L.tensor_list({k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked")})
+        h = C.c_void_p()
+        with ctx.lock:
+            L.check(ctx.lib.maa_clap_audio_create(ctx.h, C.byref(c), arr, n, C.byref(h)))
+        self.h = h
+
+    def embed(self, logmel, return_embedding=False):
+        """logmel [B, 1, T, mel_bins] -> z [B, d_proj] (unit length) [, relu(fc1) embedding [B, out_emb]]."""
+        x = _f32(logmel, self.ctx.device)
+        if x.dim() != 4 or x.shape[1] != 1 or x.shape[3] != self.cfg["mel_bins"]:
+            raise L.MaaError("ClapAudio.embed: logmel %s must be [B, 1, T, %d]" % (tuple(x.shape), self.cfg["mel_bins"]))
+        B, _, T, _ = x.shape
+        z = torch.empty(B, self.cfg["d_proj"], dtype=torch.float32, device=self.ctx.device)
+        emb = torch.empty(B, self.cfg["out_emb"], dtype=torch.float32, device=self.ctx.device) if return_embedding else None
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_clap_audio_embed(self.ctx.h, self.h, L.dptr(x), B, T,
+                                                      L.dptr(emb) if emb is not None else None, L.dptr(z)))
+        return (z, emb) if return_embedding else z
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.maa_clap_audio_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def clap_similarity(ctx, audio_embeddings, text_embeddings, scale=1.0):
+    """CLAPWrapper.compute_similarity (CLAPWrapper.py:207-215): [Na, D], [Nt, D] -> [Na, Nt] = scale * audio @ text^T."""
+    a, t = _f32(audio_embeddings, ctx.device), _f32(text_embeddings, ctx.device)
+    if a.dim() != 2 or t.dim() != 2 or a.shape[1] != t.shape[1]:
+        raise L.MaaError("clap_similarity: embeddings %s / %s must be [N, D] with one D" % (tuple(a.shape), tuple(t.shape)))
+    out = torch.empty(a.shape[0], t.shape[0], dtype=torch.float32, device=ctx.device)
+    with ctx.lock:
+        L.check(ctx.lib.maa_clap_similarity(ctx.h, L.dptr(a), L.dptr(t), a.shape[0], t.shape[0], a.shape[1], float(scale),
+                                            L.dptr(out)))
+    return out
+
+
+class Spectral:
+    """maa_spectral handle: waveform [B, n] -> log-mel (framed DFT GEMM -> |.|^p -> mel GEMM -> log), exact fp32.
+    cfg: n_fft, hop, n_mels, pad_mode ("constant" | "reflect"), power (1 | 2), log_kind ("db" | "transforms_16000"),
+    amin, ref, out_layout ("btm" = [B, frames, n_mels] | "bmt" = [B, n_mels, frames]); basis [2 n_freq, n_fft], melw
+    [n_mels, n_freq] are host matrices (audiogpt_amd/mel.py builds them)."""
+
+    def __init__(self, ctx, cfg, basis, melw):
+        self.ctx, self.cfg = ctx, dict(cfg)
+        c = L.maa_spectral_config()
+        c.n_fft, c.hop, c.n_freq, c.n_mels = cfg["n_fft"], cfg["hop"], cfg["n_fft"] // 2 + 1, cfg["n_mels"]
+        c.pad_mode = {"constant": 0, "reflect": 1}[cfg["pad_mode"]]
+        c.power = int(cfg["power"])
+        c.log_kind = {"db": 0, "transforms_16000": 1}[cfg["log_kind"]]
+        c.amin, c.ref = float(cfg["amin"]), float(cfg.get("ref", 1.0))
+        c.out_layout = {"btm": 0, "bmt": 1}[cfg["out_layout"]]
+        bt, bp = L.host_f32(torch.as_tensor(basis))
+        mt, mp = L.host_f32(torch.as_tensor(melw))
+        if tuple(bt.shape) != (2 * c.n_freq, c.n_fft) or tuple(mt.shape) != (c.n_mels, c.n_freq):
+            raise L.MaaError("Spectral: basis %s / melw %s do not match the configuration" % (tuple(bt.shape), tuple(mt.shape)))
+        h = C.c_void_p()
+        with ctx.lock:
+            L.check(ctx.lib.maa_spectral_create(ctx.h, C.byref(c), bp, mp, C.byref(h)))
+        self.h = h
+
+    def frames(self, n):
+        return 1 + n // self.cfg["hop"]
+
+    def forward(self, wav):
+        x = _f32(wav, self.ctx.device)
+        if x.dim() == 1:
+            x = x[None]
+        B, n = x.shape
+        T, M = self.frames(n), self.cfg["n_mels"]
+        out = torch.empty((B, T, M) if self.cfg["out_layout"] == "btm" else (B, M, T), dtype=torch.float32,
+                          device=self.ctx.device)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_spectral_forward(self.ctx.h, self.h, L.dptr(x), B, n, L.dptr(out)))
+        return out
+
+    __call__ = forward
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.maa_spectral_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Resampler:
+    """maa_resampler handle: torchaudio.transforms.Resample(orig, new) with its default sinc / Hann kernel bank
+    (kernels [new/g, 2 width + orig/g], built on the host by audiogpt_amd/clap.sinc_resample_kernel), exact fp32."""
+
+    def __init__(self, ctx, orig, new, width, kernels):
+        self.ctx = ctx
+        kt, kp = L.host_f32(torch.as_tensor(kernels))
+        self.orig, self.new = int(orig), int(new)
+        if kt.dim() != 2 or kt.shape[0] != self.new or kt.shape[1] != 2 * width + self.orig:
+            raise L.MaaError("Resampler: kernel bank %s must be [new, 2 width + orig]" % (tuple(kt.shape),))
+        h = C.c_void_p()
+        with ctx.lock:
+            L.check(ctx.lib.maa_resampler_create(ctx.h, self.orig, self.new, int(width), kt.shape[1], kp, C.byref(h)))
+        self.h = h
+
+    def forward(self, wav):
+        x = _f32(wav, self.ctx.device)
+        if x.dim() == 1:
+            x = x[None]
+        B, n = x.shape
+        out = torch.empty(B, -(-self.new * n // self.orig), dtype=torch.float32, device=self.ctx.device)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_resampler_forward(self.ctx.h, self.h, L.dptr(x), B, n, L.dptr(out)))
+        return out
+
+    __call__ = forward
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.maa_resampler_destroy(self.h)
             self.h = None
 
     def __del__(self):

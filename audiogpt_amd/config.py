@@ -109,11 +109,18 @@ OPENCLIP_VITH14_IMAGE = dict(kind="image", layers=32, width=1280, heads=16, mlp_
 # 24 layers, embed_dim 1024): FrozenGlobalNormOpenCLIPEmbedder.forward -- I2A's unconditional prompt (audio-chatgpt.py:238)
 OPENCLIP_VITH14_TEXT = dict(kind="clip_text", layers=24, width=1024, heads=16, mlp_dim=4096, d_proj=1024, vocab=49408,
                             max_positions=77, ln_eps=1e-5, sot=49406, eot=49407)
-# CLAP audio branch of the best-of-n scorer (wav_evaluation/models/CLAPWrapper.py, CLAP/config.yml): Cnn14 on a 64-bin
-# log-mel of 5 s at 44.1 kHz (window 1024, hop 320 -> 690 frames), 2048-d embedding -> Projection -> 1024.  Oracle
-# groundwork for the rest of SURVEY 8f / N4 only (no device implementation yet).
+# CLAP audio branch of the best-of-n scorer (wav_evaluation/models/CLAPWrapper.py, useful_ckpts/CLAP/config.yml): Cnn14 on
+# a 64-bin log-mel at 44.1 kHz (window 1024, hop 320), 2048-d embedding -> Projection -> 1024.  `frames` is only the
+# length of the golden test case (690 frames = 5 s); the scorer's own clips are `duration` * the INPUT sample rate long.
 CLAP_AUDIO_CNN14 = dict(mel_bins=64, channels=(64, 128, 256, 512, 1024, 2048), out_emb=2048, d_proj=1024, classes_num=527,
                         sample_rate=44100, window_size=1024, hop_size=320, fmin=50, fmax=14000, frames=690)
+
+
+# The whole scorer as T2A.select_best_audio builds it (audio-chatgpt.py:185-199; useful_ckpts/CLAP/config.yml):
+# text side = the same BERT + Projection architecture as CLAP_TEXT, padded to text_len with an attention mask
+CLAP_SCORER = dict(text=dict(CLAP_TEXT, max_length=100), audio=CLAP_AUDIO_CNN14, sampling_rate=44100, duration=9, text_len=100,
+                   window_size=1024, hop_size=320, mel_bins=64, fmin=50, fmax=14000, amin=1e-10, ref=1.0,
+                   resample=dict(lowpass_filter_width=6, rolloff=0.99))
 
 
 def small(cfg, **over):

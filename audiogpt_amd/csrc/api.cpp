@@ -28,6 +28,15 @@ struct maa_diffnet {
 struct maa_encoder {
     std::unique_ptr<maa::Encoder> m;
 };
+struct maa_clap_audio {
+    std::unique_ptr<maa::ClapAudio> m;
+};
+struct maa_spectral {
+    std::unique_ptr<maa::Spectral> m;
+};
+struct maa_resampler {
+    std::unique_ptr<maa::Resampler> m;
+};
 
 namespace {
 
@@ -369,6 +378,94 @@ int maa_encoder_image(maa_ctx* ctx, maa_encoder* e, const float* d_img, int B, f
         bind(ctx);
         MAA_CHECK(e && d_img && d_out && B > 0, "bad encoder_image arguments");
         e->m->image(ctx->c, d_img, B, d_out);
+    });
+}
+
+int maa_encoder_text_cls(maa_ctx* ctx, maa_encoder* e, const int* d_ids, int B, int L, float* d_out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(e && d_ids && d_out && B > 0 && L > 0, "bad encoder_text_cls arguments");
+        e->m->text_cls(ctx->c, d_ids, B, L, d_out);
+    });
+}
+
+int maa_clap_audio_create(maa_ctx* ctx, const maa_clap_audio_config* cfg, const maa_tensor* tensors, int n_tensors,
+                          maa_clap_audio** out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(cfg && out && cfg->mel_bins > 0 && cfg->n_blocks > 0 && cfg->n_blocks <= 8 && cfg->out_emb > 0 &&
+                      cfg->d_proj > 0 && cfg->d_proj % 4 == 0 && cfg->bn_eps > 0.f,
+                  "bad clap_audio config");
+        for (int i = 0; i < cfg->n_blocks; ++i) MAA_CHECK(cfg->channels[i] > 0, "bad clap_audio channel list");
+        auto sd = to_state_dict(tensors, n_tensors);
+        auto* a = new maa_clap_audio;
+        a->m.reset(new maa::ClapAudio(*cfg, sd, ctx->c.dtype));
+        *out = a;
+    });
+}
+int maa_clap_audio_destroy(maa_clap_audio* a) {
+    return guarded([&] { delete a; });
+}
+int maa_clap_audio_embed(maa_ctx* ctx, maa_clap_audio* a, const float* d_logmel, int B, int T, float* d_embedding,
+                         float* d_z) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(a && d_logmel && d_z && B > 0 && T > 0, "bad clap_audio_embed arguments");
+        a->m->embed(ctx->c, d_logmel, B, T, d_embedding, d_z);
+    });
+}
+int maa_clap_similarity(maa_ctx* ctx, const float* d_audio, const float* d_text, int Na, int Nt, int D, float scale,
+                        float* d_out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(d_audio && d_text && d_out && Na > 0 && Nt > 0 && D > 0, "bad clap_similarity arguments");
+        maa::launch_similarity(ctx->c, d_audio, d_text, Na, Nt, D, scale, d_out);
+    });
+}
+
+int maa_spectral_create(maa_ctx* ctx, const maa_spectral_config* cfg, const float* h_basis, const float* h_melw,
+                        maa_spectral** out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(cfg && h_basis && h_melw && out, "bad spectral arguments");
+        MAA_CHECK(cfg->n_fft > 0 && cfg->n_fft % 4 == 0 && cfg->hop > 0 && cfg->hop % 4 == 0 && cfg->n_freq == cfg->n_fft / 2 + 1 &&
+                      cfg->n_mels > 0 && (cfg->pad_mode == 0 || cfg->pad_mode == 1) && (cfg->power == 1 || cfg->power == 2) &&
+                      (cfg->log_kind == 0 || cfg->log_kind == 1) && cfg->amin > 0.f && (cfg->out_layout == 0 || cfg->out_layout == 1),
+                  "bad spectral config (n_fft and hop must be multiples of 4)");
+        auto* s = new maa_spectral;
+        s->m.reset(new maa::Spectral(*cfg, h_basis, h_melw));
+        *out = s;
+    });
+}
+int maa_spectral_destroy(maa_spectral* s) {
+    return guarded([&] { delete s; });
+}
+int maa_spectral_forward(maa_ctx* ctx, maa_spectral* s, const float* d_wav, int B, int n, float* d_out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(s && d_wav && d_out && B > 0 && n > 0, "bad spectral_forward arguments");
+        MAA_CHECK(s->m->config().pad_mode == 0 || n > s->m->config().n_fft / 2, "signal too short for reflect padding");
+        s->m->forward(ctx->c, d_wav, B, n, d_out);
+    });
+}
+
+int maa_resampler_create(maa_ctx* ctx, int orig, int neu, int width, int klen, const float* h_kernels, maa_resampler** out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(out && h_kernels && orig > 0 && neu > 0 && width > 0 && klen > 0, "bad resampler arguments");
+        auto* r = new maa_resampler;
+        r->m.reset(new maa::Resampler(orig, neu, width, klen, h_kernels));
+        *out = r;
+    });
+}
+int maa_resampler_destroy(maa_resampler* r) {
+    return guarded([&] { delete r; });
+}
+int maa_resampler_forward(maa_ctx* ctx, maa_resampler* r, const float* d_wav, int B, int n, float* d_out) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(r && d_wav && d_out && B > 0 && n > 0, "bad resampler_forward arguments");
+        r->m->forward(ctx->c, d_wav, B, n, d_out);
     });
 }
 

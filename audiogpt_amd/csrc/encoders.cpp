@@ -189,7 +189,11 @@ struct Encoder::Impl {
     }
 
     // BertLayer x 12 (post-LN): h = LN(h + dense(attn(h))); h = LN(h + dense(gelu(dense(h))))
-    void text(Ctx& ctx, const int* ids, int B, int L, float* out) {
+    // cls = true: the scorer's TextEncoder (wav_evaluation/models/clap.py:49-53): Projection of the [CLS] row only, then
+    // CLAPWrapper's unit-length normalisation -> [B, d_proj].  (The scorer feeds BERT a padded sequence with its
+    // attention mask; masked keys get an additive finfo.min, i.e. exactly zero weight, so running the unpadded ids --
+    // what the caller passes here -- gives the same [CLS] row.)
+    void text(Ctx& ctx, const int* ids, int B, int L, float* out, bool cls = false) {
         const int W = cfg.width, F = cfg.mlp_dim, D = cfg.d_proj;
         const long long M = (long long)B * L;
         float* x = ctx.ws.alloc_f((size_t)M * W);
@@ -211,14 +215,27 @@ struct Encoder::Impl {
             linear_into(ctx, f, F, M, F, l.fc2, x, W, t, W, 0, 0, f_sp ? M : 0);
             launch_layernorm(ctx, t, M, W, l.ln2g, l.ln2b, cfg.ln_eps, h);
         }
-        // Projection on every token
-        float* e1 = ctx.ws.alloc_f((size_t)M * D);
-        float* g = ctx.ws.alloc_f((size_t)M * D);
-        float* e2 = ctx.ws.alloc_f((size_t)M * D);
-        linear_into(ctx, h, W, M, W, proj1, nullptr, 0, e1, D);
-        launch_gelu(ctx, e1, M * D, g);
-        linear_into(ctx, g, D, M, D, proj2, e1, D, e2, D);
-        launch_layernorm(ctx, e2, M, D, proj_g, proj_b, 1e-5f, out);
+        // Projection on every token (FrozenCLAPEmbedder) or on the [CLS] rows (the scorer)
+        const long long R = cls ? B : M;
+        const float* src = h;
+        if (cls) {
+            float* c = ctx.ws.alloc_f((size_t)B * W);
+            launch_gather_rows(ctx, h, (long long)L * W, B, W, c);
+            src = c;
+        }
+        float* e1 = ctx.ws.alloc_f((size_t)R * D);
+        float* g = ctx.ws.alloc_f((size_t)R * D);
+        float* e2 = ctx.ws.alloc_f((size_t)R * D);
+        linear_into(ctx, src, W, R, W, proj1, nullptr, 0, e1, D);
+        launch_gelu(ctx, e1, R * D, g);
+        linear_into(ctx, g, D, R, D, proj2, e1, D, e2, D);
+        if (cls) {
+            float* ln = ctx.ws.alloc_f((size_t)R * D);
+            launch_layernorm(ctx, e2, R, D, proj_g, proj_b, 1e-5f, ln);
+            launch_l2norm_rows(ctx, ln, B, D, out);
+        } else {
+            launch_layernorm(ctx, e2, R, D, proj_g, proj_b, 1e-5f, out);
+        }
     }
 
     // open_clip VisionTransformer.forward + L2 normalisation
@@ -277,6 +294,13 @@ void Encoder::text(Ctx& ctx, const int* d_ids, int B, int L, float* d_out) {
         run_sized(ctx, [&] { impl_->text(ctx, d_ids, B, L, d_out); });
     else
         run_sized(ctx, [&] { impl_->clip_text(ctx, d_ids, B, L, d_out); });
+}
+
+void Encoder::text_cls(Ctx& ctx, const int* d_ids, int B, int L, float* d_out) {
+    MAA_CHECK(impl_->cfg.kind == 0, "encoder_text_cls is the CLAP (BERT) tower's");
+    MAA_CHECK(L <= impl_->cfg.max_positions, "sequence longer than the position table");
+    PrecisionGuard guard(ctx, impl_->precision);
+    run_sized(ctx, [&] { impl_->text(ctx, d_ids, B, L, d_out, /*cls=*/true); });
 }
 
 void Encoder::image(Ctx& ctx, const float* d_img, int B, float* d_out) {

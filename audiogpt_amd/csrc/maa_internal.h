@@ -212,6 +212,8 @@ void launch_snake_aa(const Ctx& ctx, const float* x, int B, int L, int C, const 
 // NSF harmonic source (nsf.hip): f0 [B, T] -> sines [B, T*hop, harmonics+1] (scratch) -> har [B, T*hop]
 void launch_nsf_source(const Ctx& ctx, const float* f0, int B, int T, int hop, float sampling_rate, const float* rand_ini,
                        const float* noise, int harmonics, const float* w, const float* bias, float* sines, float* har);
+// out[i, j] = scale * <audio[i], text[j]> (spectral.hip)
+void launch_similarity(const Ctx& ctx, const float* audio, const float* text, int Na, int Nt, int D, float scale, float* out);
 void launch_leaky(const Ctx& ctx, const float* x, long long n, float slope, float* out);
 void launch_clamp_affine(const Ctx& ctx, const float* x, long long n, float mul, float add, float lo, float hi,
                          float* out);

@@ -73,8 +73,49 @@ public:
     Encoder(const maa_encoder_config& cfg, const StateDict& sd, int precision);
     ~Encoder();
     void text(Ctx& ctx, const int* d_ids, int B, int L, float* d_out);
+    void text_cls(Ctx& ctx, const int* d_ids, int B, int L, float* d_out);
     void image(Ctx& ctx, const float* d_img, int B, float* d_out);
     const maa_encoder_config& config() const;
+
+private:
+    struct Impl;
+    Impl* impl_;
+};
+
+// CLAP audio branch of the best-of-n scorer: Cnn14 from the log-mel on + Projection, unit-length rows (clap_audio.cpp)
+class ClapAudio {
+public:
+    ClapAudio(const maa_clap_audio_config& cfg, const StateDict& sd, int precision);
+    ~ClapAudio();
+    void embed(Ctx& ctx, const float* d_logmel, int B, int T, float* d_embedding, float* d_z);
+    const maa_clap_audio_config& config() const;
+
+private:
+    struct Impl;
+    Impl* impl_;
+};
+
+// framed DFT -> |.|^p -> mel filter bank -> log: the 16 kHz front end of the inpainting tool and the 44.1 kHz one of the
+// CLAP scorer (clap_audio.cpp); always exact fp32
+class Spectral {
+public:
+    Spectral(const maa_spectral_config& cfg, const float* h_basis, const float* h_melw);
+    ~Spectral();
+    void forward(Ctx& ctx, const float* d_wav, int B, int n, float* d_out);
+    const maa_spectral_config& config() const;
+
+private:
+    struct Impl;
+    Impl* impl_;
+};
+
+// torchaudio-style polyphase sinc resampler as one strided FIR-bank contraction (clap_audio.cpp); always exact fp32
+class Resampler {
+public:
+    Resampler(int orig, int neu, int width, int klen, const float* h_kernels);
+    ~Resampler();
+    long long out_length(long long n) const;
+    void forward(Ctx& ctx, const float* d_wav, int B, int n, float* d_out);
 
 private:
     struct Impl;

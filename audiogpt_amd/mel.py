@@ -1,16 +1,22 @@
-"""16 kHz log-mel front end of the inpainting tool, on the host.
+"""16 kHz log-mel front end of the inpainting tool.
 
 Restates `TRANSFORMS_16000` (text_to_audio/Make_An_Audio/ldm/data/extract_mel_spectrogram.py:15-38, 140-150) and
-`Inpaint.gen_mel_audio` (audio-chatgpt.py:468-491).  It runs once per request on a 13.6 s clip (a 1024-point STFT of 848
-frames and an 80 x 513 matrix product: ~2 ms of numpy), so it stays on the CPU; the GPU path starts at the VAE encoder.
+`Inpaint.gen_mel_audio` (audio-chatgpt.py:468-491).  Two implementations of the same arithmetic:
+  * `DeviceMelTransform` -- the product path: the framed DFT and the mel filter bank are two GEMMs on the MI355X
+    (`maa_spectral_*`, csrc/clap_audio.cpp), so a clip goes waveform -> mel -> VAE encoder -> ... without leaving the GPU;
+    this module only builds the two constant matrices (windowed DFT basis, filter bank);
+  * `transforms_16000` / `gen_mel_audio` -- the numpy restatement the device path is tested against.
 
 PARITY UNPINNED for the two pieces that live in a third-party dependency absent from this image -- librosa (listed
-without a version in the reference's requirements.txt:25; its call style `librosa.filters.mel(sr=..., n_fft=...)` with
-keyword arguments is the 0.10 API, whose defaults are restated here):
-  * `librosa.stft(x, n_fft=1024, hop_length=256)`: centre padding n_fft // 2 on both sides with pad_mode="constant"
-    (zeros: the default since 0.10; it was "reflect" up to 0.9.2 -- `PAD_MODE` below switches), periodic Hann window
+without a version in the reference's requirements.txt:25):
+  * `librosa.stft(x, n_fft=1024, hop_length=256)`: centre padding n_fft // 2 on both sides, periodic Hann window
     (scipy.signal.get_window("hann", 1024, fftbins=True)), one-sided FFT, frame t covers samples
-    [t hop - 512, t hop + 512) of the signal, 1 + len(x) // hop frames;
+    [t hop - 512, t hop + 512) of the signal, 1 + len(x) // hop frames.  `PAD_MODE`: the padding is "reflect" up to
+    librosa 0.9.2 and zeros ("constant") from 0.10.  The reference's environment is 0.9.x -- audio-chatgpt.py:814 calls
+    `librosa.resample(y, sr, 22050)` positionally, which 0.10 rejects (keyword-only), and requirements.txt pins
+    resampy==0.2.2 (0.9's resampler backend), torchaudio==0.12.1 and numpy==1.23.1 (mid-2022) -- so "reflect" is the
+    default; AUDIOGPT_AMD_STFT_PAD=constant (or `pad_mode=`) selects the 0.10 behaviour.  Only the first and last two
+    frames of a clip differ between the two;
   * `librosa.filters.mel(sr, n_fft, n_mels=80, fmin=125, fmax=7600)`: Slaney mel scale (linear below 1 kHz with
     200/3 Hz per mel, logarithmic above with step log(6.4) / 27), triangular filters between consecutive mel
     frequencies evaluated at the FFT bin centres, Slaney area normalisation 2 / (f[i+2] - f[i]).
@@ -21,6 +27,8 @@ not against librosa itself.
 `librosa.resample` (resampy "kaiser_best" in 0.9.2) is replaced by scipy.signal.resample_poly when the input is not
 already at 16 kHz -- a different (polyphase Kaiser) low-pass; at 16 kHz no resampling happens, as in the reference.
 """
+import os
+
 import numpy as np
 
 SAMPLE_RATE = 16000
@@ -29,7 +37,7 @@ HOP = N_FFT // 4
 N_MELS = 80
 FMIN, FMAX = 125.0, 7600.0
 MEL_LEN = 848
-PAD_MODE = "constant"       # librosa >= 0.10; "reflect" reproduces librosa <= 0.9.2
+PAD_MODE = os.environ.get("AUDIOGPT_AMD_STFT_PAD", "reflect")      # librosa <= 0.9.2 (the reference's); "constant" = librosa >= 0.10
 
 
 def hz_to_mel(f):
@@ -95,10 +103,22 @@ def transforms_16000(wav):
     return np.clip(x, 0, 1.0)
 
 
-def gen_mel_audio(input_audio):
-    """Inpaint.gen_mel_audio (audio-chatgpt.py:468-491): (sr, int16 samples, mono or [n, 2] stereo) -> [80, 849] mel of
-    the first 848 * 256 samples (zero-extended when shorter; the reference pads by a full clip length, so the frame count
-    then depends on the input -- reproduced)."""
+def dft_basis(n_fft=N_FFT, window="hann"):
+    """The one-sided DFT as a real matrix [2 (n_fft // 2 + 1), n_fft] with the periodic analysis window folded in: rows
+    0 .. n_fft/2 = w[n] cos(2 pi k n / N), the next n_fft/2 + 1 rows = -w[n] sin(2 pi k n / N) (the layout of torchlibrosa's
+    stft.conv_real.weight / conv_imag.weight; the STFT of a frame is basis @ frame)."""
+    from scipy.signal import get_window
+    win = get_window(window, n_fft, fftbins=True).astype(np.float64)
+    k = np.arange(n_fft // 2 + 1, dtype=np.float64)[:, None]
+    n = np.arange(n_fft, dtype=np.float64)[None, :]
+    # k n mod N keeps the argument of cos / sin small (exact in fp64 for these sizes)
+    ang = 2.0 * np.pi * np.mod(k * n, n_fft) / n_fft
+    return np.concatenate([np.cos(ang) * win, -np.sin(ang) * win], axis=0).astype(np.float32)
+
+
+def prepare_wav(input_audio):
+    """The host half of Inpaint.gen_mel_audio (audio-chatgpt.py:473-489): (sr, int16 samples, mono or [n, 2] stereo) ->
+    float32 mono at 16 kHz, zero-extended / cropped to the clip length."""
     sr, wav = input_audio
     wav = np.asarray(wav).astype(np.float32, order="C") / 32768.0
     if wav.ndim == 2:
@@ -114,4 +134,32 @@ def gen_mel_audio(input_audio):
         wav = np.pad(wav, (0, input_len), constant_values=0)
     else:
         wav = wav[:input_len]
-    return transforms_16000(wav)
+    return wav
+
+
+def gen_mel_audio(input_audio):
+    """Inpaint.gen_mel_audio (audio-chatgpt.py:468-491) in numpy: -> [80, 849] mel of the first 848 * 256 samples
+    (zero-extended when shorter; the reference pads by a full clip length, so the frame count then depends on the
+    input -- reproduced)."""
+    return transforms_16000(prepare_wav(input_audio))
+
+
+class DeviceMelTransform:
+    """TRANSFORMS_16000 on the MI355X: `(sr, wav) -> [80, frames]` like `gen_mel_audio`, the STFT and the filter bank as
+    two GEMMs of the library (exact fp32).  `ctx`: the backend context of the model the mel is for."""
+
+    def __init__(self, ctx, pad_mode=None):
+        from .backend import Spectral
+        self.pad_mode = pad_mode or PAD_MODE
+        cfg = dict(n_fft=N_FFT, hop=HOP, n_mels=N_MELS, pad_mode=self.pad_mode, power=1, log_kind="transforms_16000",
+                   amin=1e-5, ref=1.0, out_layout="bmt")
+        self.spectral = Spectral(ctx, cfg, dft_basis(N_FFT), mel_filterbank())
+
+    def mel(self, wav):
+        """float waveform [n] or [B, n] at 16 kHz -> device tensor [B, 80, 1 + n // 256] in [0, 1]."""
+        return self.spectral.forward(wav)
+
+    def __call__(self, sr, wav):
+        import torch
+        x = torch.from_numpy(np.ascontiguousarray(prepare_wav((sr, wav))))
+        return self.mel(x)[0].cpu().numpy()

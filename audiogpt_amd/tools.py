@@ -12,8 +12,11 @@ Pluggable:
     `encode` / `forward_img` / `preprocess`; when the checkpoint carries `cond_stage_model.*` weights the device towers of
     ldm/encoders.py are built from them (`tokenizer=` / `preprocess=` supply the host-side halves); otherwise a seeded
     stand-in with the encoders' output statistics (ldm/latent_diffusion.SyntheticEmbedder)
-  * CLAP best-of-n re-ranking (`select_best_audio`, audio-chatgpt.py:185-199): pass `scorer=`; without one the
-    first sample is returned
+  * CLAP best-of-n re-ranking (`select_best_audio`, audio-chatgpt.py:185-199): `clap=` takes a CLAPWrapper
+    (audiogpt_amd/clap.py: resampler, log-mel, Cnn14, BERT [CLS] and the similarity all on the device) or the CLAP
+    checkpoint's state_dict (then `clap_tokenizer=` supplies the host-side tokenizer); a checkpoint dict that carries
+    `clap_model.*` entries builds it too; `scorer=` overrides with any callable (prompt, wav, sr) -> score.  With none of
+    them the first sample is returned (the reference always loads CLAP_weights_2022.pth)
   * wav / image file I/O uses scipy + a minimal PNG/colormap path only if PIL / soundfile are absent
 """
 import os
@@ -42,12 +45,18 @@ def _write_wav(path, wav, sr):
 
 class T2A:
     def __init__(self, device, ckpt_state_dict=None, vocoder_dir=None, cond_stage_model=None, scorer=None,
-                 precision=None, tokenizer=None):
+                 precision=None, tokenizer=None, clap=None, clap_tokenizer=None):
         print("Initializing Make-An-Audio to %s" % device)
         self.device = device
         self.sampler = self._initialize_model(C.LDM_T2A, ckpt_state_dict, device, cond_stage_model, precision, tokenizer)
         self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=self.sampler.model.ctx)
         self.scorer = scorer
+        if clap is None and ckpt_state_dict is not None and any(k.startswith("clap_model.") for k in ckpt_state_dict):
+            clap = {k[len("clap_model."):]: v for k, v in ckpt_state_dict.items() if k.startswith("clap_model.")}
+        if isinstance(clap, dict):
+            from .clap import CLAPWrapper
+            clap = CLAPWrapper(state_dict=clap, tokenizer=clap_tokenizer or tokenizer, ctx=self.sampler.model.ctx)
+        self.clap_model = clap
 
     def _initialize_model(self, config, ckpt, device, cond_stage_model=None, precision=None, tokenizer=None):
         model = LatentDiffusionAudio(config, device=device, state_dict=ckpt, cond_stage_model=cond_stage_model,
@@ -73,10 +82,23 @@ class T2A:
         return self.select_best_audio(text, wav_list)
 
     def select_best_audio(self, prompt, wav_list):
-        if self.scorer is None:
+        if self.scorer is not None:
+            scores = [float(self.scorer(prompt, wav, sr)) for sr, wav in wav_list]
+            return wav_list[int(np.argmax(scores))]
+        if self.clap_model is None:
             return wav_list[0]
-        scores = [float(self.scorer(prompt, wav, sr)) for sr, wav in wav_list]
-        return wav_list[int(np.argmax(scores))]
+        clap_model = self.clap_model                                                  # audio-chatgpt.py:186-199
+        text_embeddings = clap_model.get_text_embeddings([prompt])
+        score_list = []
+        for data in wav_list:
+            sr, wav = data
+            audio_embeddings = clap_model.get_audio_embeddings([(torch.FloatTensor(wav), sr)], resample=True)
+            score = clap_model.compute_similarity(audio_embeddings, text_embeddings,
+                                                  use_logit_scale=False).squeeze().cpu().numpy()
+            score_list.append(score)
+        max_index = np.array(score_list).argmax()
+        print(score_list, max_index)
+        return wav_list[max_index]
 
     def inference(self, text, seed=55, scale=1.5, ddim_steps=100, n_samples=3, W=624, H=80):
         melbins, mel_len = 80, 624
@@ -140,11 +162,12 @@ class Inpaint:
                                      precision=precision)
         self.sampler = DDIMSampler(model)
         self.vocoder = VocoderBigVGAN(vocoder_dir, device=device, ctx=model.ctx)
-        # gen_mel_audio + TRANSFORMS_16000 (audio-chatgpt.py:468-491, extract_mel_spectrogram.py:140-150): the host-side
-        # restatement in audiogpt_amd/mel.py unless the caller plugs in the librosa-backed original
+        # gen_mel_audio + TRANSFORMS_16000 (audio-chatgpt.py:468-491, extract_mel_spectrogram.py:140-150) on the device
+        # (STFT and filter bank as two GEMMs, audiogpt_amd/mel.DeviceMelTransform) unless the caller plugs in the
+        # librosa-backed original
         if mel_transform is None:
-            from .mel import gen_mel_audio
-            mel_transform = lambda sr, wav: gen_mel_audio((sr, wav))      # noqa: E731
+            from .mel import DeviceMelTransform
+            mel_transform = DeviceMelTransform(model.ctx)
         self.mel_transform = mel_transform
 
     def make_batch_sd(self, mel, mask, num_samples=1):

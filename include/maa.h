@@ -254,6 +254,70 @@ int maa_encoder_text(maa_ctx* ctx, maa_encoder* e, const int* d_ids, int B, int 
 /* kind 1: d_img [B, 3, image, image] -> d_out [B, d_proj], rows L2-normalised */
 int maa_encoder_image(maa_ctx* ctx, maa_encoder* e, const float* d_img, int B, float* d_out);
 
+/* kind 0 only: the scorer's text side -- TextEncoder.forward (wav_evaluation/models/clap.py:49-53: BERT, the [CLS] row,
+ * Projection) followed by CLAPWrapper.get_text_embeddings' normalisation (CLAPWrapper.py:177-182).  d_ids holds the
+ * UNPADDED token ids: the reference pads to text_len and passes the attention mask, under which the padded keys weigh
+ * exactly zero, so the [CLS] row is the same.  -> d_out [B, d_proj], rows L2-normalised */
+int maa_encoder_text_cls(maa_ctx* ctx, maa_encoder* e, const int* d_ids, int B, int L, float* d_out);
+
+/* ---- CLAP best-of-n scorer, audio side (T2A.select_best_audio, audio-chatgpt.py:185-199) -------------------
+ * replaces: AudioEncoder.forward (wav_evaluation/models/clap.py:22-39) from the log-mel on -- Cnn14.forward after its two
+ * extractors (wav_evaluation/models/audio.py:150-176, eval mode) + Projection -- and CLAPWrapper.get_audio_embeddings'
+ * normalisation (CLAPWrapper.py:184-189).
+ * tensors: `audio_encoder.`-relative keys: base.bn0.*, base.conv_block{1..n}.{conv1,conv2}.weight,
+ * base.conv_block{i}.{bn1,bn2}.{weight,bias,running_mean,running_var}, base.fc1.*, projection.{linear1,linear2}.weight,
+ * projection.layer_norm.* (fc_audioset and the extractors' frozen tables are not used here) */
+typedef struct maa_clap_audio_config {
+    int mel_bins, n_blocks, channels[8];
+    int out_emb, d_proj;
+    float bn_eps;                   /* 1e-5 (nn.BatchNorm2d default) */
+} maa_clap_audio_config;
+typedef struct maa_clap_audio maa_clap_audio;
+int maa_clap_audio_create(maa_ctx* ctx, const maa_clap_audio_config* cfg, const maa_tensor* tensors, int n_tensors,
+                          maa_clap_audio** out);
+int maa_clap_audio_destroy(maa_clap_audio* a);
+/* d_logmel [B, 1, T, mel_bins] -> d_z [B, d_proj] (unit length); d_embedding [B, out_emb] = relu(fc1(.)) or NULL */
+int maa_clap_audio_embed(maa_ctx* ctx, maa_clap_audio* a, const float* d_logmel, int B, int T, float* d_embedding,
+                         float* d_z);
+/* replaces: CLAPWrapper.compute_similarity (CLAPWrapper.py:207-215): d_out [Na, Nt] = scale * audio @ text^T
+ * (scale = 1 for use_logit_scale = False, exp(logit_scale) otherwise) */
+int maa_clap_similarity(maa_ctx* ctx, const float* d_audio, const float* d_text, int Na, int Nt, int D, float scale,
+                        float* d_out);
+
+/* ---- log-mel front ends ------------------------------------------------------------------------------------
+ * replaces: torchlibrosa Spectrogram + LogmelFilterBank as Cnn14 builds them (wav_evaluation/models/audio.py:123-131)
+ * and TRANSFORMS_16000 (ldm/data/extract_mel_spectrogram.py:15-38, 140-150; Inpaint.gen_mel_audio, audio-chatgpt.py:468-491):
+ * centre padding (n_fft / 2 on both sides) -> framed DFT -> re^2 + im^2 (power 2) or its root (power 1) -> mel filter
+ * bank -> logarithm.  frames = 1 + n / hop.
+ *   h_basis [2 n_freq][n_fft]: rows 0..n_freq-1 the real, n_freq.. the imaginary DFT rows, analysis window folded in
+ *     (= torchlibrosa's stft.conv_real.weight / conv_imag.weight, which a CLAP checkpoint carries)
+ *   h_melw  [n_mels][n_freq]: the mel filter bank (librosa.filters.mel; = logmel_extractor.melW transposed)
+ *   log_kind 0: 10 log10(max(amin, x)) - 10 log10(max(amin, ref))     (power_to_db, top_db = None)
+ *   log_kind 1: clip((20 log10(max(amin, x)) - 20 + 100) / 100, 0, 1)  (TRANSFORMS_16000)
+ *   out_layout 0: d_out [B, frames, n_mels] (= Cnn14's [B, 1, T, mel_bins]);  1: [B, n_mels, frames] (the LDM's mel image)
+ * Always exact fp32, whatever the context's precision mode. */
+typedef struct maa_spectral_config {
+    int n_fft, hop, n_freq, n_mels;
+    int pad_mode;                   /* 0 zeros (librosa >= 0.10), 1 reflect (torchlibrosa; librosa <= 0.9.2) */
+    int power;                      /* 1 or 2 */
+    int log_kind;
+    float amin, ref;
+    int out_layout;
+} maa_spectral_config;
+typedef struct maa_spectral maa_spectral;
+int maa_spectral_create(maa_ctx* ctx, const maa_spectral_config* cfg, const float* h_basis, const float* h_melw,
+                        maa_spectral** out);
+int maa_spectral_destroy(maa_spectral* s);
+int maa_spectral_forward(maa_ctx* ctx, maa_spectral* s, const float* d_wav, int B, int n, float* d_out);
+
+/* replaces: torchaudio.transforms.Resample(orig, new) as CLAPWrapper.resample_and_duration applies it
+ * (CLAPWrapper.py:103-110): orig / new already divided by their gcd; h_kernels [new][klen], klen = 2 width + orig is
+ * torchaudio's sinc kernel bank (built on the host: audiogpt_amd/clap.py).  d_wav [B, n] -> d_out [B, ceil(new n / orig)] */
+typedef struct maa_resampler maa_resampler;
+int maa_resampler_create(maa_ctx* ctx, int orig, int neu, int width, int klen, const float* h_kernels, maa_resampler** out);
+int maa_resampler_destroy(maa_resampler* r);
+int maa_resampler_forward(maa_ctx* ctx, maa_resampler* r, const float* d_wav, int B, int n, float* d_out);
+
 /* ---- single-operator entry points (parity tests and profiling of individual kernels) ------------ */
 /* y[M,N] = A[M,K] * W^T (+bias) with W given as torch Linear weight [N,K] on the HOST; A, y on device */
 int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w, const float* h_bias, int N,

@@ -646,6 +646,97 @@ def clap_audio_case(name, cfg, manifest, B=2, seed=14):
     print(name, "embedding", tuple(emb.shape), "absmax", float(emb.abs().max()), "z absmax", float(z.abs().max()))
 
 
+def clap_score_case(name, cfg, n_audio=3, seed=21):
+    """The best-of-n scorer on the reference's OWN wav_evaluation classes (T2A.select_best_audio, audio-chatgpt.py:185-199):
+    TextEncoder (wav_evaluation/models/clap.py:41-53) fed what CLAPWrapper.preprocess_text builds -- input_ids padded to
+    text_len, token_type_ids, attention_mask -- with `AutoModel.from_pretrained` answered by transformers' BertModel
+    (what it instantiates for bert-base-uncased; no download here), AudioEncoder (clap.py:22-39 over
+    wav_evaluation/models/audio.py's Cnn14) entered after its two torchlibrosa extractors (absent), the two
+    normalisations of CLAPWrapper (:177-189) and compute_similarity(use_logit_scale=False) (:207-215).
+    The clips are 9 * 16000 samples long at hop 320: 451 frames -- the scorer's own shape."""
+    import importlib.util
+    import transformers
+    from transformers import BertConfig, BertModel
+    tl = types.ModuleType("torchlibrosa")
+    st = types.ModuleType("torchlibrosa.stft")
+    st.Spectrogram = st.LogmelFilterBank = lambda *a, **k: torch.nn.Identity()
+    tl.stft = st
+    sys.modules.setdefault("torchlibrosa", tl)
+    sys.modules.setdefault("torchlibrosa.stft", st)
+    pkg = "refwaveval"
+    stub = types.ModuleType(pkg)
+    stub.__path__ = []
+    sys.modules[pkg] = stub
+    real_from_pretrained = transformers.AutoModel.from_pretrained
+    transformers.AutoModel.from_pretrained = staticmethod(lambda name, *a, **k: BertModel(BertConfig()))
+    try:
+        mods = {}
+        for m in ("audio", "clap"):
+            sp = importlib.util.spec_from_file_location(pkg + "." + m, os.path.join(MAA, "wav_evaluation/models/%s.py" % m))
+            mods[m] = importlib.util.module_from_spec(sp)
+            sys.modules[pkg + "." + m] = mods[m]
+            sp.loader.exec_module(mods[m])
+        a = cfg["audio"]
+        clap = mods["clap"].CLAP(audioenc_name="Cnn14", sample_rate=cfg["sampling_rate"], window_size=cfg["window_size"],
+                                 hop_size=cfg["hop_size"], mel_bins=cfg["mel_bins"], fmin=cfg["fmin"], fmax=cfg["fmax"],
+                                 classes_num=a["classes_num"], out_emb=a["out_emb"], text_model="bert-base-uncased",
+                                 transformer_embed_dim=cfg["text"]["width"], d_proj=a["d_proj"]).eval()
+    finally:
+        transformers.AutoModel.from_pretrained = real_from_pretrained
+    tsd = WT.make_clap_text_state_dict(cfg["text"], seed=seed)
+    asd = WT.make_clap_audio_state_dict(a, seed=seed + 1)
+    sd = {"caption_encoder." + k: v for k, v in tsd.items()}
+    sd.update({"audio_encoder." + k: v for k, v in asd.items()})
+    sd["logit_scale"] = torch.tensor(math.log(1 / 0.07))
+    missing = clap.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all("pooler" in k or k.endswith("position_ids") for k in missing.missing_keys), missing
+    # preprocess_text's tensors for one prompt of 9 word pieces: [CLS] w1..w9 [SEP] [PAD]...
+    L = cfg["text_len"]
+    g = torch.Generator().manual_seed(41)
+    n_tok = 9
+    ids = torch.zeros(1, L, dtype=torch.long)
+    ids[0, 0] = 101
+    ids[0, 1:1 + n_tok] = torch.randint(1000, cfg["text"]["vocab"], (n_tok,), generator=g)
+    ids[0, 1 + n_tok] = 102
+    mask = torch.zeros(1, L, dtype=torch.long)
+    mask[0, :n_tok + 2] = 1
+    tok = {"input_ids": ids, "token_type_ids": torch.zeros_like(ids), "attention_mask": mask}
+    frames = 9 * 16000 // cfg["hop_size"] + 1
+    # three clearly different "clips": level, spread and a spectral tilt per clip (dB-like values)
+    scales = torch.tensor([12.0, 6.0, 18.0])[:n_audio]
+    offsets = torch.tensor([-30.0, -10.0, -45.0])[:n_audio]
+    tilts = torch.tensor([0.0, -0.4, 0.3])[:n_audio]
+    logmel = torch.randn(n_audio, 1, frames, cfg["mel_bins"], generator=torch.Generator().manual_seed(42)) * \
+        scales.view(-1, 1, 1, 1) + offsets.view(-1, 1, 1, 1) + tilts.view(-1, 1, 1, 1) * torch.arange(cfg["mel_bins"]).view(1, 1, 1, -1)
+    with torch.no_grad():
+        te = clap.caption_encoder(tok)                                                 # CLAPWrapper._get_text_embeddings
+        te = te / torch.norm(te, dim=-1, keepdim=True)
+        te = te / torch.norm(te, dim=-1, keepdim=True)                                 # (:181) a second time
+        base = clap.audio_encoder.base
+        x = base.bn0(logmel.transpose(1, 3)).transpose(1, 3)
+        for i, blk in enumerate((base.conv_block1, base.conv_block2, base.conv_block3, base.conv_block4, base.conv_block5,
+                                 base.conv_block6)):
+            x = blk(x, pool_size=(2, 2) if i < 5 else (1, 1), pool_type="avg")
+        x = torch.mean(x, dim=3)
+        x = torch.max(x, dim=2)[0] + torch.mean(x, dim=2)
+        emb = torch.relu(base.fc1(x))
+        ae = clap.audio_encoder.projection(emb)
+        ae = ae / torch.norm(ae, dim=-1, keepdim=True)
+        ae = ae / torch.norm(ae, dim=-1, keepdim=True)
+        sim = (te @ ae.T).T                                                            # compute_similarity, no logit scale
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), input_ids=ids[0, :n_tok + 2].numpy(), text_len=L, logmel_seed=42,
+                        scales=scales.numpy(), offsets=offsets.numpy(), tilts=tilts.numpy(), frames=frames, text_embedding=te.numpy(), audio_embedding=ae.numpy(), similarity=sim.numpy())
+    print(name, "similarity", sim.reshape(-1).tolist())
+
+
+def main_clap_score_only():
+    """`python tests/golden/make_golden.py clapscore`: the best-of-n scorer through the reference's wav_evaluation classes."""
+    torch.set_num_threads(8)
+    _install_shims()
+    clap_score_case("clap_score", C.CLAP_SCORER)
+    print("torch", torch.__version__)
+
+
 def main_clap_audio_only():
     """`python tests/golden/make_golden.py clapaudio`: the CLAP audio-branch case (groundwork, SURVEY 8f / N4 scorer)."""
     torch.set_num_threads(8)
@@ -756,4 +847,4 @@ def main_ddim_variants_only():
 
 if __name__ == "__main__":
     {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "diffsinger": main_diffsinger_only,
-     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only, "cliptext": main_clip_text_only, "clapaudio": main_clap_audio_only}.get(" ".join(sys.argv[1:]), main)()
+     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only, "cliptext": main_clip_text_only, "clapaudio": main_clap_audio_only, "clapscore": main_clap_score_only}.get(" ".join(sys.argv[1:]), main)()

@@ -237,6 +237,53 @@ def test_mel_front_end_against_the_transformers_restatement_of_librosa():
         assert s.shape == m.shape and np.abs(s - m).max() < 1e-5 * np.abs(m).max()
 
 
+def test_scorer_front_end_tables():
+    """Host-built constants of the device front ends: the windowed DFT basis against numpy's FFT and
+    torch.stft, the 44.1 kHz filter bank against transformers.audio_utils, torchaudio's resampling kernel bank by its
+    defining properties (torchaudio is absent: unpinned), and the default STFT padding."""
+    import numpy as np
+    import torch
+    from scipy.signal import get_window
+
+    from audiogpt_amd import config as C
+    from audiogpt_amd import mel as M
+    from audiogpt_amd.clap import sinc_resample_kernel
+    assert M.PAD_MODE == os.environ.get("AUDIOGPT_AMD_STFT_PAD", "reflect")          # librosa 0.9.x, the reference's
+    basis = M.dft_basis(1024)
+    assert basis.shape == (1026, 1024) and basis.dtype == np.float32
+    x = np.random.RandomState(0).randn(3000).astype(np.float32)
+    F = np.fft.rfft(x[:1024] * get_window("hann", 1024, fftbins=True))
+    y = basis.astype(np.float64) @ x[:1024]
+    assert np.abs(y[:513] - F.real).max() < 1e-5 and np.abs(y[513:] - F.imag).max() < 1e-5
+    # the framed-GEMM formulation == torch.stft (centre, reflect), power spectrogram
+    xt = torch.from_numpy(x)[None]
+    st = torch.stft(xt, 1024, hop_length=320, window=torch.hann_window(1024, periodic=True), center=True, pad_mode="reflect",
+                    return_complex=True)
+    fr = torch.nn.functional.pad(xt[:, None], (512, 512), mode="reflect")[:, 0].unfold(1, 1024, 320)
+    Y = fr.double() @ torch.from_numpy(basis).double().T
+    P = (Y[..., :513] ** 2 + Y[..., 513:] ** 2)[0].T
+    ref = (st.real ** 2 + st.imag ** 2)[0].double()
+    assert P.shape == ref.shape == (513, 1 + 3000 // 320) and float((P - ref).abs().max()) < 1e-4 * float(ref.max())
+    a = C.CLAP_SCORER
+    au = pytest.importorskip("transformers.audio_utils")
+    fb = au.mel_filter_bank(num_frequency_bins=513, num_mel_filters=a["mel_bins"], min_frequency=a["fmin"], max_frequency=a["fmax"],
+                            sampling_rate=a["sampling_rate"], norm="slaney", mel_scale="slaney")
+    mine = M.mel_filterbank(sr=a["sampling_rate"], n_fft=1024, n_mels=a["mel_bins"], fmin=a["fmin"], fmax=a["fmax"])
+    assert np.abs(fb.T - mine).max() < 1e-8
+    # resampler: 16 k -> 44.1 k reduces to 160 -> 441; phase 0 is (nearly) the identity tap; every phase has DC gain ~1;
+    # a 1 kHz tone comes out as a 1 kHz tone of the same amplitude
+    k, width = sinc_resample_kernel(16000, 44100)
+    assert k.shape == (441, 2 * width + 160) and width == 7
+    assert abs(k[0, width] - 0.99) < 1e-6 and np.abs(k.sum(1) - 1.0).max() < 2e-3
+    t = np.arange(16000) / 16000.0
+    tone = np.sin(2 * np.pi * 1000.0 * t).astype(np.float32)
+    xp = np.pad(tone, (width, width + 160))
+    frames = np.lib.stride_tricks.sliding_window_view(xp, k.shape[1])[::160]
+    out = (frames @ k.T).reshape(-1)[:44100]
+    want = np.sin(2 * np.pi * 1000.0 * np.arange(44100) / 44100.0)
+    assert np.abs(out[2000:42000] - want[2000:42000]).max() < 5e-3
+
+
 def test_product_tree_never_touches_the_oracle_or_the_reference_tree():
     """The oracle is test infrastructure: nothing under audiogpt_amd/ (or include/) may import or name it, and nothing
     that runs on the GPU box (product, bench.py, __graft_entry__.py, tests other than the golden generator) may read

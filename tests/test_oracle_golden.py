@@ -300,3 +300,28 @@ def test_clap_audio_branch_matches_reference(golden):
     _close(z.numpy(), g["z"], 2e-6, "clap audio embedding")
     s = O_ca.similarity(z, z)
     _close(np.diag(s.numpy()), np.ones(2), 1e-5, "self similarity")
+
+
+def test_clap_scorer_matches_the_reference_wav_evaluation_classes(golden):
+    """the whole best-of-n score on the reference's own wav_evaluation classes (golden `clap_score`).  The
+    reference feeds BERT the prompt padded to text_len with its attention mask; the oracle (and the device) run the real
+    tokens only -- this is the proof that the two give the same [CLS] embedding."""
+    from oracle import clap_audio as O_ca
+    g = golden("clap_score")
+    cfg = C.CLAP_SCORER
+    tsd = WT.make_clap_text_state_dict(cfg["text"], seed=21)
+    asd = WT.make_clap_audio_state_dict(cfg["audio"], seed=22)
+    assert int(g["text_len"]) == cfg["text_len"] and len(g["input_ids"]) < cfg["text_len"]
+    frames = int(g["frames"])
+    assert frames == cfg["duration"] * 16000 // cfg["hop_size"] + 1
+    sc, of, ti = (torch.from_numpy(g[k]).view(-1, 1, 1, 1) for k in ("scales", "offsets", "tilts"))
+    logmel = torch.randn(3, 1, frames, cfg["mel_bins"], generator=torch.Generator().manual_seed(int(g["logmel_seed"]))) * sc + \
+        of + ti * torch.arange(cfg["mel_bins"]).view(1, 1, 1, -1)
+    with torch.no_grad():
+        te = O_ca.text_embedding(tsd, cfg["text"], torch.from_numpy(g["input_ids"]))
+        ae = O_ca.clap_audio_embed(asd, cfg["audio"], logmel)
+    _close(te.numpy(), g["text_embedding"], 2e-6, "scorer text embedding (unpadded ids vs padded + mask)")
+    _close(ae.numpy(), g["audio_embedding"], 2e-6, "scorer audio embedding")
+    sim = O_ca.similarity(ae, te).numpy()
+    _close(sim, g["similarity"], 2e-6, "similarity")
+    assert int(sim.argmax()) == int(g["similarity"].argmax())
