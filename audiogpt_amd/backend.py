@@ -447,6 +447,8 @@ class DiffNet:
         B, _, M, T = x.shape
         if M != self.cfg["in_dims"] or tuple(cond.shape) != (B, self.cfg["hidden_size"], T):
             raise L.MaaError("plms_sample: x %s / cond %s do not fit the denoiser" % (tuple(x.shape), tuple(cond.shape)))
+        if B > 256:
+            raise L.MaaError("plms_sample: at most 256 samples per call (got %d)" % B)
         ac = np.ascontiguousarray(np.asarray(alphas_cumprod), dtype=np.float32)
         a = L.maa_plms_args()
         a.B, a.T, a.K_step, a.interval, a.timesteps = B, T, int(K_step), int(interval), int(ac.shape[0])

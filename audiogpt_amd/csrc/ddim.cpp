@@ -6,10 +6,13 @@
 //   concat conditioning is cat([x, c], dim=1) (ldm/models/diffusion/ddpm.py:1404-1406)
 // Nothing returns to the host inside the loop: per-step scalars (t, a_t, a_prev, sqrt(1-a_t)) are rows of
 // device tables copied into fixed slots, so every step launches the same kernels on the same addresses and
-// the step can be captured once as a hipGraph and replayed.
+// the step can be captured once as a hipGraph and replayed.  The latent and the concat conditioning are staged in the
+// context's own slab, so the captured step does not depend on the caller's buffers and is KEPT across sample() calls
+// (Ctx::ddim_graph): a later call with the same model, shapes and guidance replays it without capturing again.
 #include "models.h"
 
 #include <cmath>
+#include <cstring>
 
 namespace maa {
 
@@ -38,11 +41,16 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
         cf[3] = std::sqrt(1.0f - a.h_alphas[i]);       // ddim.py:52 (fp32 sqrt of fp32 1-a)
     }
     auto up = [](size_t n) { return (n + 63) / 64 * 64; };      // floats, 256-byte aligned pieces
+    const size_t n_cc = concat ? (size_t)a.B * (per_in - per) : 0;
     const size_t o_tab = 0, o_step = o_tab + up(h_tab.size()), o_t = o_step + 64, o_coef = o_t + up(nB),
-                 o_xin = o_coef + 64, o_eps = o_xin + up((size_t)nB * per_in), total = o_eps + up((size_t)nB * per);
+                 o_xin = o_coef + 64, o_eps = o_xin + up((size_t)nB * per_in), o_x = o_eps + up((size_t)nB * per),
+                 o_cc = o_x + up((size_t)a.B * per), total = o_cc + up(n_cc);
     float* slab = static_cast<float*>(ctx.sampler_scratch.get(total * sizeof(float), ctx.stream));
     float *tab_t = slab + o_tab, *tab_coef = slab + o_tab + a.S, *cur_t = slab + o_t, *cur_coef = slab + o_coef,
-          *xin = slab + o_xin, *eps = slab + o_eps;
+          *xin = slab + o_xin, *eps = slab + o_eps, *xs = slab + o_x, *ccs = slab + o_cc;
+    // the trajectory runs on the slab's copy of the latent (and of the concat conditioning)
+    MAA_HIP(hipMemcpyAsync(xs, d_x, (size_t)a.B * per * 4, hipMemcpyDeviceToDevice, ctx.stream));
+    if (concat) MAA_HIP(hipMemcpyAsync(ccs, a.d_concat, n_cc * 4, hipMemcpyDeviceToDevice, ctx.stream));
     int* d_step = reinterpret_cast<int*>(slab + o_step);
     const int h_step = a.S - 1;                        // ddim.py:143-145: flipped timesteps, index = total - i - 1
     MAA_HIP(hipMemcpyAsync(slab + o_tab, h_tab.data(), h_tab.size() * 4, hipMemcpyHostToDevice, ctx.stream));
@@ -58,44 +66,65 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
 
     // one step: identical launches on identical addresses whatever the step (the index lives on the device)
     auto step_body = [&]() {
-        launch_ddim_prepare(ctx, d_x, concat ? a.d_concat : nullptr, a.B, nB, per, per_in - per, tab_t, tab_coef, d_step,
-                            xin, cur_t, cur_coef);
+        launch_ddim_prepare(ctx, xs, concat ? ccs : nullptr, a.B, nB, per, per_in - per, tab_t, tab_coef, d_step, xin,
+                            cur_t, cur_coef);
         unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps);
-        launch_ddim_update(ctx, d_x, eps, cfg ? eps + a.B * per : nullptr, a.scale, cur_coef, (long long)a.B * per, d_x,
+        launch_ddim_update(ctx, xs, eps, cfg ? eps + a.B * per : nullptr, a.scale, cur_coef, (long long)a.B * per, xs,
                            nullptr, d_step);
     };
 
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    try {
-        for (int i = 0; i < a.S; ++i) {
-            if (!a.use_graph || i == 0) {
-                step_body();                      // first step eager: sizes the workspace before any capture
-            } else {
-                if (!exec) {
-                    MAA_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeRelaxed));
-                    try {
-                        step_body();
-                    } catch (...) {
-                        hipGraph_t dead = nullptr;
-                        (void)hipStreamEndCapture(ctx.stream, &dead);
-                        if (dead) (void)hipGraphDestroy(dead);
-                        throw;
-                    }
-                    MAA_HIP(hipStreamEndCapture(ctx.stream, &graph));
-                    MAA_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-                }
-                MAA_HIP(hipGraphLaunch(exec, ctx.stream));
+    // Everything a captured step depends on besides the device-side state it reads: the model and its own buffers, the
+    // shapes, the guidance scale, the slab (every slot's offset is a function of the numbers listed) and the workspace.
+    // (The workspace base / capacity go in AFTER the first eager step, which may grow it.)
+    auto make_key = [&]() {
+        std::vector<unsigned long long> k;
+        unet.graph_key(k);
+        unsigned scale_bits;
+        static_assert(sizeof(scale_bits) == sizeof(a.scale), "float bits");
+        std::memcpy(&scale_bits, &a.scale, 4);
+        for (unsigned long long v : {(unsigned long long)a.S, (unsigned long long)a.B, (unsigned long long)a.C, (unsigned long long)a.H,
+                                     (unsigned long long)a.W, (unsigned long long)a.Cc, (unsigned long long)a.L,
+                                     (unsigned long long)cfg, (unsigned long long)concat, (unsigned long long)scale_bits,
+                                     (unsigned long long)ctx.dtype, (unsigned long long)reinterpret_cast<uintptr_t>(slab),
+                                     (unsigned long long)reinterpret_cast<uintptr_t>(ctx.stream),
+                                     (unsigned long long)reinterpret_cast<uintptr_t>(ctx.ws.base()),
+                                     (unsigned long long)ctx.ws.capacity()})
+            k.push_back(v);
+        return k;
+    };
+
+    StepGraph& sg = ctx.ddim_graph;
+    int first = 0;
+    if (a.use_graph && sg.exec && sg.key == make_key()) {
+        // same step as the last call's: replay from the first step on (the workspace the graph was captured over is still
+        // this context's, at the same address and size)
+    } else if (a.use_graph) {
+        sg.clear();
+        step_body();                      // first step eager: sizes the workspace before any capture
+        first = 1;
+        if (a.S > 1) {
+            MAA_HIP(hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeRelaxed));
+            try {
+                step_body();
+            } catch (...) {
+                hipGraph_t dead = nullptr;
+                (void)hipStreamEndCapture(ctx.stream, &dead);
+                if (dead) (void)hipGraphDestroy(dead);
+                throw;
             }
+            MAA_HIP(hipStreamEndCapture(ctx.stream, &sg.graph));
+            MAA_HIP(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+            sg.key = make_key();
         }
-        MAA_HIP(hipStreamSynchronize(ctx.stream));   // the host tables go out of scope; the call returns a finished latent
-    } catch (...) {
-        if (exec) (void)hipGraphExecDestroy(exec);
-        if (graph) (void)hipGraphDestroy(graph);
-        throw;
     }
-    if (exec) (void)hipGraphExecDestroy(exec);
-    if (graph) (void)hipGraphDestroy(graph);
+    for (int i = first; i < a.S; ++i) {
+        if (a.use_graph)
+            MAA_HIP(hipGraphLaunch(sg.exec, ctx.stream));
+        else
+            step_body();
+    }
+    MAA_HIP(hipMemcpyAsync(d_x, xs, (size_t)a.B * per * 4, hipMemcpyDeviceToDevice, ctx.stream));
+    MAA_HIP(hipStreamSynchronize(ctx.stream));   // the host tables go out of scope; the call returns a finished latent
 }
 
 }  // namespace maa

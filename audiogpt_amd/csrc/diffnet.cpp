@@ -202,6 +202,7 @@ void DiffNet::plms_sample(Ctx& ctx, const maa_plms_args& a, float* d_x) {
     Impl& m = *impl_;
     MAA_CHECK(a.B > 0 && a.T > 0 && a.K_step > 0 && a.interval > 0 && a.timesteps >= a.K_step && a.h_alphas_cumprod && a.d_cond,
               "bad plms arguments");
+    MAA_CHECK(a.B <= 256, "plms: at most 256 samples per call (the step-advance kernel is one workgroup)");
     PrecisionGuard pg(ctx, m.precision);
     const int B = a.B, T = a.T, M = m.cfg.in_dims;
     const long long n = (long long)B * M * T;

@@ -325,11 +325,7 @@ void launch_dh(const Ctx& ctx, const FlashArgs& a, int B) {
     constexpr size_t tr = (size_t)4 * 32 * (DM + 1) * sizeof(float);
     constexpr size_t lds = kv > tr ? kv : tr;
     auto kern = flash_attn_kernel<DH, TERMS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     dim3 grid((unsigned)((a.Nq + 127) / 128), (unsigned)(B * a.heads));
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, a);
 }

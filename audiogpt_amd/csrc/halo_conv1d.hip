@@ -238,18 +238,8 @@ void launch_c(const Ctx& ctx, const HaloArgs& a) {
     constexpr size_t lds = (size_t)(TL + 2 * HMAX) * (C / 32) * 128 + (size_t)NSB * C * 128;
     static_assert(lds <= 163840, "LDS per workgroup");
     auto kern = halo_conv1d_kernel<C, TL, NSB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    static int cus[16] = {0};
-    int& nc = cus[ctx.device & 15];
-    if (!nc) {
-        hipDeviceProp_t prop;
-        MAA_HIP(hipGetDeviceProperties(&prop, ctx.device));
-        nc = prop.multiProcessorCount;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
+    const int nc = device_cu_count(ctx.device);
     const int per_cu = (int)(163840 / lds) < 3 ? (int)(163840 / lds) : 3;
     long long grid = (long long)nc * (per_cu < 1 ? 1 : per_cu);
     if (grid > a.tiles) grid = a.tiles;

@@ -330,11 +330,7 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
     constexpr int planes = TERMS == 1 ? 1 : 2;
     constexpr size_t lds = (size_t)2 * planes * (BM + BN) * BKT * sizeof(unsigned short);
     auto kern = igemm_bf16_kernel<BM, BN, WGM, WGN, TERMS, AS, BS, BKT, PF>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, p, ntiles, Nb);
 }
 

@@ -237,11 +237,7 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
     dim3 grid((unsigned)((long long)mtiles * ntiles));
     constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
     auto kern = igemm_dma_kernel<BM, BN, WGM, WGN, NS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, p, ntiles, Nb);
 }
 

@@ -404,16 +404,7 @@ __global__ void splitk_reduce_kernel(const IGemm p, const float* __restrict__ pa
 
 // Persistent grids: at most this many workgroups per CU's worth of LDS, times the CUs.  MAA_DMA2_PERSIST=0 launches one
 // workgroup per work item instead (A/B).
-int cu_count(const Ctx& ctx) {
-    static int n[16] = {0};
-    int& c = n[ctx.device & 15];
-    if (!c) {
-        hipDeviceProp_t prop;
-        MAA_HIP(hipGetDeviceProperties(&prop, ctx.device));
-        c = prop.multiProcessorCount;
-    }
-    return c;
-}
+int cu_count(const Ctx& ctx) { return device_cu_count(ctx.device); }
 
 template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE>
 void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
@@ -430,11 +421,7 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
     constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
     static_assert(lds <= 163840, "LDS per workgroup");
     auto kern = igemm_dma2_kernel<BM, BN, WGM, WGN, NS, PIPE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MAA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     const long long items = (long long)tiles * S;
     const char* pe = std::getenv("MAA_DMA2_PERSIST");
     long long grid = items;

@@ -41,6 +41,7 @@ public:
     void release(size_t m) { off_ = m; }
     float* alloc_f(size_t n_floats);
     size_t capacity() const { return cap_; }
+    const void* base() const { return base_; }
     size_t high_water() const { return high_; }
     size_t mark_high() const { return run_high_; }   // high-water since the last reset()
     // when true, alloc only counts (dry run to size the slab)
@@ -81,6 +82,10 @@ struct ProfScope {     // records an event pair around the launches issued durin
     size_t idx_ = 0;
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); safe from several launching threads
+void ensure_dynamic_lds(const void* kernel, int device, int bytes);
+int device_cu_count(int device);      // multiProcessorCount, cached per device
+
 // grow-only device buffer owned by a context / model (growing synchronises the stream first: never inside a capture)
 struct DevSlab {
     void* p = nullptr;
@@ -92,7 +97,22 @@ struct DevSlab {
     DevSlab& operator=(const DevSlab&) = delete;
 };
 
+// The captured DDIM step of the last sample() call on a context, kept across calls: a call whose step would launch the
+// same kernels on the same addresses with the same arguments (same model, shapes, guidance, buffers) replays it instead
+// of capturing and instantiating again.  `key` lists everything the step's launches depend on.
+struct StepGraph {
+    std::vector<unsigned long long> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    void clear();
+    ~StepGraph() { clear(); }
+    StepGraph() = default;
+    StepGraph(const StepGraph&) = delete;
+    StepGraph& operator=(const StepGraph&) = delete;
+};
+
 struct Ctx {
+    StepGraph ddim_graph;
     DevSlab sampler_scratch;  // DDIM loop state (tables, step slots, UNet input, eps): reused by every sample() call
     Profiler* prof = nullptr;
     float* zeros = nullptr;   // 256 B zero page (device), source of masked tile loads

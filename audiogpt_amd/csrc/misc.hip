@@ -6,6 +6,8 @@
 //                                       filter.py:28-57,86-94}, activations.py:107-119
 #include "maa_internal.h"
 
+#include <mutex>
+
 #include <cstdlib>
 
 #include <cmath>
@@ -329,16 +331,16 @@ void launch_ddim_prepare(const Ctx& ctx, const float* x, const float* concat, in
                 xin, cur_t, cur_coef);
 }
 
-static bool g_fir_uploaded[16] = {false};
+static std::once_flag g_fir_once[64];      // one upload of the FIR taps per device (thread-safe: contexts on several threads)
 void launch_snake_aa(const Ctx& ctx, const float* x, int B, int L, int C, const float* inv_beta, const float* alpha,
                      float* out) {
     if (ctx.ws.dry) return;
-    if (!g_fir_uploaded[ctx.device & 15]) {
+    MAA_CHECK(ctx.device >= 0 && ctx.device < 64, "device index");
+    std::call_once(g_fir_once[ctx.device], [] {
         float f[12];
         kaiser_sinc_filter12(f);
         MAA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fir12), f, sizeof(f)));
-        g_fir_uploaded[ctx.device & 15] = true;
-    }
+    });
     static const bool untiled = std::getenv("MAA_SNAKE_UNTILED") != nullptr;      // A/B and bit-identity test
     if (!untiled && (C % 64 == 0 || C == 32) && B <= 65535) {
         ProfScope prof(ctx, "snake_aa_kernel", 0.0, 8.0 * (double)B * L * C);

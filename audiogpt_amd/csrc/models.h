@@ -21,6 +21,9 @@ public:
     size_t weight_bytes() const;
     // context pointer remembered by set_context (needed by the I2A time-embedding add)
     const float* context_ptr = nullptr;
+    // addresses / sizes of the UNet-owned buffers a captured forward reads (cross-attention K/V caches, CFG context):
+    // appended to a graph cache key
+    void graph_key(std::vector<unsigned long long>& key) const;
 
 private:
     struct Impl;

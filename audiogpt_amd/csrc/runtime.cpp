@@ -6,6 +6,8 @@
 //   ConvTranspose1d [Cin][Cout][k]  (NeuralSeq/modules/hifigan/hifigan.py:121-125)
 #include "maa_internal.h"
 
+#include <mutex>
+
 #include <cstdlib>
 #include <cstring>
 
@@ -146,6 +148,40 @@ const HostTensor& get(const StateDict& sd, const std::string& name) {
     return it->second;
 }
 bool has(const StateDict& sd, const std::string& name) { return sd.find(name) != sd.end(); }
+
+void StepGraph::clear() {
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    exec = nullptr;
+    graph = nullptr;
+    key.clear();
+}
+
+// ------------------------------------------------------------------------------------------ per-device launch state
+namespace {
+std::mutex g_launch_mu;
+std::map<std::pair<const void*, int>, int> g_lds_attr;      // (kernel, device) -> bytes already granted
+std::map<int, int> g_cus;
+}  // namespace
+
+void ensure_dynamic_lds(const void* kernel, int device, int bytes) {
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    int& have = g_lds_attr[{kernel, device}];
+    if (have >= bytes) return;
+    MAA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+}
+
+int device_cu_count(int device) {
+    std::lock_guard<std::mutex> lk(g_launch_mu);
+    int& c = g_cus[device];
+    if (!c) {
+        hipDeviceProp_t prop;
+        MAA_HIP(hipGetDeviceProperties(&prop, device));
+        c = prop.multiProcessorCount;
+    }
+    return c;
+}
 
 // ------------------------------------------------------------------------------------------ WeightStore
 WeightStore::~WeightStore() {

@@ -13,6 +13,7 @@
 //   * bias, time-embedding add, residual add and GEGLU are igemm epilogues
 #include "models.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 
@@ -70,6 +71,11 @@ struct UNet::Impl {
     float *out_g = nullptr, *out_b = nullptr;
     int emb_dim = 0, emb_total = 0;
     // cross-attention K/V cache: one [rows, 2*inner] buffer per transformer block
+    unsigned long long serial = next_serial();
+    static unsigned long long next_serial() {
+        static std::atomic<unsigned long long> n{1};
+        return n.fetch_add(1);
+    }
     std::vector<float*> kv_cache;
     std::vector<int> kv_inner;
     int kv_rows = 0, kv_len = 0, kv_batch = 0;
@@ -499,6 +505,16 @@ void UNet::set_context(Ctx& ctx, const float* context, int B, int L) {
     m.kv_batch = B;
     m.kv_len = L;
     context_ptr = context;
+}
+
+void UNet::graph_key(std::vector<unsigned long long>& key) const {
+    const Impl& m = *impl_;
+    key.push_back((unsigned long long)reinterpret_cast<uintptr_t>(this));
+    key.push_back(m.serial);                 // (a later UNet may be constructed at a freed one's address)
+    key.push_back((unsigned long long)reinterpret_cast<uintptr_t>(context_ptr));
+    key.push_back((unsigned long long)m.kv_batch);
+    key.push_back((unsigned long long)m.kv_len);
+    for (const float* p : m.kv_cache) key.push_back((unsigned long long)reinterpret_cast<uintptr_t>(p));
 }
 
 void UNet::set_context_cfg(Ctx& ctx, const float* d_uncond, const float* d_cond, int B, int L) {

@@ -335,7 +335,8 @@ Vocoder::~Vocoder() { delete impl_; }
 int Vocoder::hop() const { return impl_->hop; }
 
 void Vocoder::forward(Ctx& ctx, const float* mel, int B, int T, float* wav) {
-    MAA_CHECK(!impl_->cfg.use_pitch_embed, "this generator was built with use_pitch_embed: call maa_vocoder_forward_f0");
+    // a generator built with use_pitch_embed called without f0 simply skips the source branch, as HifiGanGenerator.forward(x,
+    // f0=None) does (hifigan.py:144-169: `if self.use_pitch_embed and f0 is not None`)
     PrecisionGuard pg(ctx, impl_->precision);
     run_sized(ctx, [&] { impl_->forward(ctx, mel, B, T, wav); });
 }

@@ -64,9 +64,10 @@ class GaussianDiffusion(object):
         return self.denoise_fn.plms_sample(x, cond, self.alphas_cumprod.cpu().numpy(), K, iv, use_graph=use_graph)
 
     @torch.no_grad()
-    def infer(self, fs2_mels, cond, noise=None, gaussian_start=False):
+    def infer(self, fs2_mels, cond, noise=None, gaussian_start=False, mel2ph=None):
         """The infer branch of forward (:244-276) after the FastSpeech2 front end: fs2_mels [B, T, M] (ret['mel_out'] of
-        fs2), cond [B, H, T] (ret['decoder_inp'].transpose(1, 2)) -> mel_out [B, T, M]."""
+        fs2), cond [B, H, T] (ret['decoder_inp'].transpose(1, 2)) -> mel_out [B, T, M]; with mel2ph [B, T] (singing) the
+        frames that belong to no phoneme are zeroed (:273-274)."""
         fs2_mels = fs2_mels.to(device=self.device, dtype=torch.float32)
         x0 = self.norm_spec(fs2_mels).transpose(1, 2)[:, None, :, :]
         t = torch.tensor([self.K_step - 1], device=self.device).long()
@@ -74,4 +75,7 @@ class GaussianDiffusion(object):
         if gaussian_start:
             x = torch.randn((cond.shape[0], 1, self.mel_bins, cond.shape[2]), device=self.device)
         x = self.sample_plms(x, cond)
-        return self.denorm_spec(x[:, 0].transpose(1, 2))
+        out = self.denorm_spec(x[:, 0].transpose(1, 2))
+        if mel2ph is not None:
+            out = out * (torch.as_tensor(mel2ph).to(out.device) > 0).float()[:, :, None]
+        return out

@@ -175,7 +175,7 @@ class HifiGAN(BaseVocoder):
     def __init__(self, hparams=None, device="cuda:0", ctx=None, state_dict=None, precision=None):
         h = dict(hparams or C.HIFIGAN_NS_512)
         h.setdefault("use_pitch_embed", False)
-        self.use_nsf = bool(h.get("use_nsf", h["use_pitch_embed"]))      # hparams['use_nsf'] of the singing configs
+        self.use_nsf = bool(h.get("use_nsf", False))      # hparams.get('use_nsf') (vocoders/hifigan.py:60): falsy when absent
         self.model = HifiGanGenerator(h, device=device, ctx=ctx, precision=precision)
         if state_dict is not None:
             self.model.load_state_dict(state_dict, strict=True)

@@ -23,9 +23,11 @@ Secondary workloads (reported under "secondary" in the same JSON line at N = 1, 
                frames), 100 DDIM steps each, every step a hipGraph replay = 188.4 audio-seconds per step.
 
 Steps overlap: `--inflight 3` (default) keeps three consecutive steps -- independent batches of 8 prompts -- in flight per GPU on
-three pipeline replicas (streams); every batch is still sampled as configs[1] says (measured: 1 / 2 / 3 in flight = 88.8 / 109.9
-/ 113.4 audio-s/s on one box).  `one_batch_in_flight` in the JSON line is
-the same measurement with the steps strictly one after another.
+three pipeline replicas (streams); every batch is still sampled as configs[1] says.  The METHOD IS PART OF THE METRIC STRING
+("... [3 batches of 8 in flight per GPU]"); `one_batch_in_flight` in the same JSON line is the strictly sequential
+measurement (one batch of 8 owning the GPU: the number comparable with round 1 and with a latency reading of configs[1]),
+`ms_per_step` is elapsed / steps (the throughput period, as the contract defines it) and `batch_latency_ms` says how long
+one batch takes from its first kernel to its waveforms under each of the two arrangements.
 
 Output: ONE JSON line on rank 0 with metric/value plus
   roofline     -- the dominant kernel (the implicit-GEMM engine): algorithmic FLOPs (2*M*N*K) of its launches / their
@@ -105,6 +107,64 @@ def cpu_baseline(ddim_steps_sample=2):
                 sample="1 prompt: %d of %d CFG DDIM steps timed and scaled (%.2f s/step), + full VAE decode (%.2f s) "
                        "+ full HiFi-GAN 624 frames (%.2f s); torch %s fp32, %d threads"
                        % (ddim_steps_sample, DDIM_STEPS, t_unet, t_vae, t_voc, torch.__version__, cores))
+
+
+def cpu_baseline_mixed(ddim_steps_sample=2, S=DDIM_STEPS):
+    """The CPU oracle on one clip of each tool of the mixed batch: `ddim_steps_sample` DDIM steps timed and scaled, the VAE
+    and BigVGAN passes in full.  Returns audio-seconds per second for (one inpaint clip + one image-to-audio clip)."""
+    from oracle import ddim as O_ddim
+    from oracle import unet as O_unet
+    from oracle import vae as O_vae
+    from oracle import vocoder as O_voc
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    vsd = WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1, with_encoder=True)
+    gsd = O_voc.fold_weight_norm(WT.make_vocoder_state_dict(C.BIGVGAN_16K, seed=3))
+    g = torch.Generator().manual_seed(77)
+    parts = {}
+    with torch.no_grad():
+        # inpaint: encode the masked mel, concat-conditioned DDIM without CFG, decode, BigVGAN over 848 frames
+        usd = WT.make_unet_state_dict(C.UNET_INPAINT, seed=5)
+        mel = torch.rand(1, 1, 80, 848, generator=g)
+        t0 = time.perf_counter()
+        mean, logvar = O_vae.encode_moments(vsd, C.VAE_DDCONFIG, mel * 2 - 1)
+        parts["inpaint_encode"] = time.perf_counter() - t0
+        x = torch.randn(1, 4, 10, 106, generator=g)
+        cc = torch.cat((mean, torch.ones(1, 1, 10, 106)), dim=1)
+        ts = torch.full((1,), 991, dtype=torch.long)
+        O_unet.unet_forward(usd, C.UNET_INPAINT, torch.cat([x, cc], 1), ts, None)
+        t0 = time.perf_counter()
+        for _ in range(ddim_steps_sample):
+            O_unet.unet_forward(usd, C.UNET_INPAINT, torch.cat([x, cc], 1), ts, None)
+        parts["inpaint_unet_step"] = (time.perf_counter() - t0) / ddim_steps_sample
+        t0 = time.perf_counter()
+        m = O_vae.decode_first_stage(vsd, C.VAE_DDCONFIG, x, 1.0)
+        parts["inpaint_decode"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O_voc.bigvgan_forward(gsd, C.BIGVGAN_16K, torch.clamp((m + 1) / 2, 0, 1)[:, 0])
+        parts["inpaint_bigvgan"] = time.perf_counter() - t0
+        # image-to-audio: CFG 3 over a one-token context
+        usd = WT.make_unet_state_dict(C.UNET_I2A, seed=4)
+        x = torch.randn(1, *LATENT, generator=g)
+        ctx2 = torch.randn(2, 1, 1024, generator=g)
+        ts = torch.full((2,), 991, dtype=torch.long)
+        O_unet.unet_forward(usd, C.UNET_I2A, torch.cat([x, x]), ts, ctx2)
+        t0 = time.perf_counter()
+        for _ in range(ddim_steps_sample):
+            O_unet.unet_forward(usd, C.UNET_I2A, torch.cat([x, x]), ts, ctx2)
+        parts["i2a_unet_step"] = (time.perf_counter() - t0) / ddim_steps_sample
+        t0 = time.perf_counter()
+        m = O_vae.decode_first_stage(vsd, C.VAE_DDCONFIG, x, 1.0)
+        parts["i2a_decode"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O_voc.bigvgan_forward(gsd, C.BIGVGAN_16K, torch.clamp((m + 1) / 2, 0, 1)[:, 0])
+        parts["i2a_bigvgan"] = time.perf_counter() - t0
+    total = S * (parts["inpaint_unet_step"] + parts["i2a_unet_step"]) + sum(v for k, v in parts.items() if "unet" not in k)
+    audio = (848 + 624) * 256 / 16000.0
+    return dict(value=audio / total, unit="audio-seconds/sec", cores=cores, kind="port",
+                sample="1 inpaint clip + 1 image-to-audio clip: %d of %d DDIM steps of each UNet timed and scaled, VAE encode / decode "
+                       "and BigVGAN in full (seconds: %s); torch %s fp32, %d threads"
+                       % (ddim_steps_sample, S, ", ".join("%s %.2f" % kv for kv in parts.items()), torch.__version__, cores))
 
 
 HIFIGAN64 = dict(B=64, T=1024, seed=7)
@@ -202,7 +262,38 @@ def run_hifigan64(dev, precision, steps, warmup, cpu_base=True, roofline=True):
     return res
 
 
-def run_mixed(dev, precision, steps, warmup, n=PROMPTS_PER_GPU, S=DDIM_STEPS, roofline=True):
+def mixed_inputs(n=PROMPTS_PER_GPU):
+    """Synthetic inputs of the mixed tool batch (CPU tensors; tests/golden/make_golden.py `mixed` replays single rows of them
+    through the reference): mels U(0,1) [n,1,80,848] with rectangle masks, L2-normalised N(0,1) image embeddings
+    [n,1,1024], one layer-normed unconditional row, posterior noise and start codes."""
+    g = torch.Generator().manual_seed(77)
+    mel = torch.rand(n, 1, 80, 848, generator=g)
+    mask = torch.zeros(n, 1, 80, 848)
+    for b in range(n):
+        t0, f0 = 100 + 40 * b, 8 + 3 * b
+        mask[b, :, f0:f0 + 40, t0:t0 + 300] = 1.0
+    emb = torch.randn(n, 1, 1024, generator=g)
+    emb = emb / emb.norm(dim=-1, keepdim=True)
+    uc = torch.nn.functional.layer_norm(torch.randn(1, 1, 1024, generator=g), (1024,)).expand(n, -1, -1).contiguous()
+    noise = torch.randn(n, 4, 10, 106, generator=g)
+    xT_inp = torch.randn(n, 4, 10, 106, generator=g)
+    xT_i2a = torch.from_numpy(np.random.RandomState(55).randn(n, *LATENT)).float()
+    return mel, mask, emb, uc, noise, xT_inp, xT_i2a
+
+
+def mixed_inpaint(inp, mel, mask, noise, xT, S, use_graph=True):
+    """tools.Inpaint.inpaint, batched, on pipeline `inp` -> (waveforms, composited mels, latents)."""
+    mom = inp.vae.encode_moments((1 - mask) * mel * 2 - 1)
+    mean, logvar = mom.chunk(2, dim=1)
+    zc = mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise
+    cc = torch.nn.functional.interpolate(mask * 2 - 1, size=zc.shape[-2:])
+    z = inp.sample_latents(xT, S=S, concat=torch.cat((zc, cc), dim=1), use_graph=use_graph)
+    pred = inp.decode(z)[:, None]
+    comp = (1 - mask) * mel + mask * pred
+    return inp.vocode(comp[:, 0]), comp[:, 0], z
+
+
+def run_mixed(dev, precision, steps, warmup, n=PROMPTS_PER_GPU, S=DDIM_STEPS, roofline=True, cpu_base=True):
     """BASELINE configs[4] on one GPU: a mixed tool batch, each tool's DDIM step captured as a hipGraph.
       inpaint: n masked mels [80, 848] (U(0,1), random rectangle masks) -> VAE encode + posterior sample -> concat-conditioned
                DDIM over [n, 9, 10, 106] without CFG (inpaint beta schedule) -> decode -> composite with the input mel ->
@@ -213,35 +304,15 @@ def run_mixed(dev, precision, steps, warmup, n=PROMPTS_PER_GPU, S=DDIM_STEPS, ro
     from audiogpt_amd.pipeline import MakeAnAudio
     inp = MakeAnAudio(dev, ldm=C.LDM_INPAINT, vocoder_cfg=C.BIGVGAN_16K, seeds=(5, 1, 3), with_encoder=True, precision=precision)
     i2a = MakeAnAudio(dev, ldm=C.LDM_I2A, vocoder_cfg=C.BIGVGAN_16K, seeds=(4, 1, 3), precision=precision)
-    g = torch.Generator().manual_seed(77)
-    mel = torch.rand(n, 1, 80, 848, generator=g)
-    mask = torch.zeros(n, 1, 80, 848)
-    for b in range(n):
-        t0, f0 = 100 + 40 * b, 8 + 3 * b
-        mask[b, :, f0:f0 + 40, t0:t0 + 300] = 1.0
-    mel, mask = mel.to(dev), mask.to(dev)
-    emb = torch.randn(n, 1, 1024, generator=g)
-    emb = (emb / emb.norm(dim=-1, keepdim=True)).to(dev)
-    uc = torch.nn.functional.layer_norm(torch.randn(1, 1, 1024, generator=g), (1024,)).expand(n, -1, -1).contiguous().to(dev)
-    noise = torch.randn(n, 4, 10, 106, generator=g).to(dev)
-    xT_inp = torch.randn(n, 4, 10, 106, generator=g).to(dev)
-    xT_i2a = torch.from_numpy(np.random.RandomState(55).randn(n, *LATENT)).float().to(dev)
+    mel, mask, emb, uc, noise, xT_inp, xT_i2a = (t.to(dev) for t in mixed_inputs(n))
 
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=1)
+    pool = ThreadPoolExecutor(max_workers=1, initializer=torch.cuda.set_device, initargs=(dev,))
 
     def one_step():
         # the two tools are independent requests on their own pipelines (streams): image -> audio runs beside inpainting
         f2 = pool.submit(lambda: i2a.generate(xT_i2a, emb, uc, 3.0, S)[0])
-        # inpaint (tools.Inpaint.inpaint, batched)
-        mom = inp.vae.encode_moments((1 - mask) * mel * 2 - 1)
-        mean, logvar = mom.chunk(2, dim=1)
-        zc = mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise
-        cc = torch.nn.functional.interpolate(mask * 2 - 1, size=zc.shape[-2:])
-        z = inp.sample_latents(xT_inp, S=S, concat=torch.cat((zc, cc), dim=1))
-        pred = inp.decode(z)[:, None]
-        comp = (1 - mask) * mel + mask * pred
-        w1 = inp.vocode(comp[:, 0])
+        w1 = mixed_inpaint(inp, mel, mask, noise, xT_inp, S)[0]
         return w1, f2.result()
 
     for _ in range(warmup):
@@ -262,10 +333,7 @@ def run_mixed(dev, precision, steps, warmup, n=PROMPTS_PER_GPU, S=DDIM_STEPS, ro
     if roofline:
         inp.ctx.prof_begin()
         i2a.ctx.prof_begin()
-        mom = inp.vae.encode_moments((1 - mask) * mel * 2 - 1)
-        zc = mom.chunk(2, dim=1)[0]
-        z = inp.sample_latents(xT_inp, S=S, concat=torch.cat((zc, torch.nn.functional.interpolate(mask * 2 - 1, size=zc.shape[-2:])), dim=1), use_graph=False)
-        inp.vocode(inp.decode(z))
+        mixed_inpaint(inp, mel, mask, noise, xT_inp, S, use_graph=False)
         i2a.generate(xT_i2a, emb, uc, 3.0, S, use_graph=False)
         rows = inp.ctx.prof_end()
         for k, v in i2a.ctx.prof_end().items():
@@ -277,6 +345,8 @@ def run_mixed(dev, precision, steps, warmup, n=PROMPTS_PER_GPU, S=DDIM_STEPS, ro
         res["roofline"] = roofline_of(rows, precision)
     inp.close()
     i2a.close()
+    if cpu_base:
+        res["cpu_baseline"] = cpu_baseline_mixed(S=S)
     return res
 
 
@@ -320,7 +390,7 @@ def main():
     if args.workload == "mixed":
         assert world == 1, "run one mixed batch per GPU (replicas) -- no collective in this workload"
         print(json.dumps(run_mixed(dev, args.precision, args.steps, args.warmup, args.prompts_per_gpu, args.ddim_steps,
-                                   not args.no_roofline)), flush=True)
+                                   not args.no_roofline, not args.no_cpu_baseline)), flush=True)
         return
     dist = None
     if world > 1:
@@ -344,7 +414,8 @@ def main():
     pipes = [MakeAnAudio(dev, precision=args.precision, stream=None if args.legacy_streams else torch.cuda.Stream(dev))
              for _ in range(inflight)]
     pipe = pipes[0]
-    pool = ThreadPoolExecutor(max_workers=inflight)
+    # worker threads start with torch's thread-local device at 0: pin them to this rank's GPU (no stray context on GPU 0)
+    pool = ThreadPoolExecutor(max_workers=inflight, initializer=torch.cuda.set_device, initargs=(dev,))
     n = args.prompts_per_gpu
     S = args.ddim_steps
     use_graph = not args.no_graph
@@ -368,7 +439,7 @@ def main():
             done = torch.cuda.Event()
             if p_.stream is None:
                 wav = p_.generate_here(x_T, c_, uc_, CFG_SCALE, S, use_graph=use_graph)[0]
-                done.record()
+                done.record(torch.cuda.current_stream(dev))
             else:
                 with torch.cuda.stream(p_.stream):
                     p_.stream.wait_event(ready)
@@ -379,8 +450,14 @@ def main():
             return wav, done
         return generate
 
+    comm_events = {"C1_broadcast": [], "C2_gather": []}      # (start, end) event pairs around the two collectives, per step
+
     def conditioning():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         c, uc = broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape)          # C1: RCCL broadcast (no-op at N = 1)
+        e1.record()
+        comm_events["C1_broadcast"].append((e0, e1))
         ready = torch.cuda.Event()
         ready.record()
         return c, uc, ready
@@ -390,7 +467,12 @@ def main():
         cur = torch.cuda.current_stream()
         cur.wait_event(done)
         wav.record_stream(cur)
-        return gather_waveforms(wav, dist, counts=counts)                                      # C2: gather to rank 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = gather_waveforms(wav, dist, counts=counts)                                       # C2: gather to rank 0
+        e1.record()
+        comm_events["C2_gather"].append((e0, e1))
+        return out
 
     def run_steps(k):
         """k steps; step i runs on pipeline i % inflight while the previous inflight-1 steps are still sampling
@@ -405,6 +487,8 @@ def main():
 
     run_steps(args.warmup * inflight)      # W untimed steps on every replica (each sizes its workspace, builds its graphs)
     barrier()
+    for v in comm_events.values():
+        v.clear()
     t0 = time.perf_counter()
     out = run_steps(args.steps)
     barrier()
@@ -414,9 +498,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # device time of the two collectives of a step (events on the main thread's stream, this rank): their share of a step is
+    # what the first multi-GPU run should look at before anything else
+    comm_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)) for k, v in comm_events.items()}
     audio_s = pipe.audio_seconds(n * world, CLIP_FRAMES) * args.steps
+    method = "" if inflight == 1 else " [%d independent batches of %d prompts in flight per GPU]" % (inflight, n)
     result = {
-        "metric": "generated audio-seconds/sec (10s clip, 100 DDIM steps)",
+        "metric": "generated audio-seconds/sec (10s clip, 100 DDIM steps)" + method,
         "value": audio_s / elapsed, "unit": "audio-seconds/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * elapsed / args.steps,
@@ -428,6 +516,9 @@ def main():
                    "audio_seconds_per_step": pipe.audio_seconds(n * world, CLIP_FRAMES), "hipgraph": use_graph,
                    "batches_in_flight": inflight,
                    "parallelism": "prompt-sharded x%d (RCCL bcast cond / gather wav)" % world},
+        "comm_ms_per_step": {k: round(v, 4) for k, v in comm_ms.items()},
+        # Little's law for the overlapped arrangement: `inflight` batches are resident for `inflight` throughput periods
+        "batch_latency_ms": {"in_flight": 1000.0 * elapsed / args.steps * inflight},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -473,12 +564,13 @@ def main():
         one = time.perf_counter() - t0
         result["one_batch_in_flight"] = {"value": pipe.audio_seconds(n, CLIP_FRAMES) * k1 / one, "ms_per_step": 1e3 * one / k1,
                                          "steps": k1}
+        result["batch_latency_ms"]["alone"] = 1e3 * one / k1
     if rank == 0 and world == 1 and not args.no_secondary:
         for p_ in pipes:
             p_.close()
         result["secondary"] = {}
         for name, fn in (("hifigan64", lambda: run_hifigan64(dev, args.precision, 3, 1, not args.no_cpu_baseline, not args.no_roofline)),
-                         ("mixed", lambda: run_mixed(dev, args.precision, 2, 1, roofline=not args.no_roofline))):
+                         ("mixed", lambda: run_mixed(dev, args.precision, 2, 1, roofline=not args.no_roofline, cpu_base=not args.no_cpu_baseline))):
             try:
                 result["secondary"][name] = fn()
             except Exception as e:      # never lose the headline line to a secondary workload

@@ -737,6 +737,93 @@ def main_clap_score_only():
     print("torch", torch.__version__)
 
 
+def mixed_case(name, row_i2a=3, row_inp=6, S=100, n_batch=8):
+    """BASELINE configs[4] as bench.py feeds it on one GPU (bench.mixed_inputs): ONE row of each tool through the reference's
+    own classes, 100 DDIM steps.
+      image-to-audio (audio-chatgpt.py:232-261): DDIMSampler over custom_openaimodel.UNetModel with a one-token context,
+        guidance 3 -> Decoder -> clamp -> BigVGAN (624 frames)
+      inpaint (:500-528): Encoder + quant_conv -> posterior sample (the row's noise) -> cat with the resized mask ->
+        concat-conditioned DDIMSampler (x_T given) -> Decoder -> compositing with the input mel -> BigVGAN (848 frames)
+    ~3 minutes on 8 cores."""
+    from argparse import Namespace
+    import bench
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.model import Decoder, Encoder
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+    from vocoder.bigvgan.models import BigVGAN
+    mel, mask, emb, uc, noise, xT_inp, xT_i2a = bench.mixed_inputs(n_batch)
+    dd = C.VAE_DDCONFIG
+    kw = dict(ch=dd["ch"], out_ch=dd["out_ch"], ch_mult=tuple(dd["ch_mult"]), num_res_blocks=dd["num_res_blocks"],
+              attn_resolutions=list(dd["attn_resolutions"]), in_channels=dd["in_channels"], resolution=dd["resolution"],
+              z_channels=dd["z_channels"], double_z=dd["double_z"])
+    dec, enc = Decoder(**kw).eval(), Encoder(**kw).eval()
+    vsd = WT.make_vae_state_dict(dd, seed=1)
+    dec.load_state_dict(WT.strip_prefix(vsd, "decoder."), strict=True)
+    enc.load_state_dict(WT.strip_prefix(vsd, "encoder."), strict=True)
+    pq = torch.nn.Conv2d(dd["embed_dim"], dd["z_channels"], 1)
+    qc = torch.nn.Conv2d(2 * dd["z_channels"], 2 * dd["embed_dim"], 1)
+    pq.load_state_dict(WT.strip_prefix(vsd, "post_quant_conv."))
+    qc.load_state_dict(WT.strip_prefix(vsd, "quant_conv."))
+    cfg = C.BIGVGAN_16K
+    gen = BigVGAN(Namespace(**{k: (list(map(list, v)) if k == "resblock_dilation_sizes" else
+                                   (list(v) if isinstance(v, tuple) else v)) for k, v in cfg.items()})).eval()
+    missing, unexpected = gen.load_state_dict(WT.make_vocoder_state_dict(cfg, seed=3), strict=False)
+    assert not unexpected and all(k.endswith("filter") for k in missing), (missing, unexpected)
+
+    def sampler_for(unet, ldm):
+        concat = ldm["conditioning_key"] == "concat"
+
+        class Shim:
+            def __init__(self):
+                betas = make_beta_schedule("linear", ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+                ac = np.cumprod(1.0 - betas, axis=0)
+                self.num_timesteps = ldm["timesteps"]
+                self.betas = torch.tensor(betas, dtype=torch.float32)
+                self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+                self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+                self.device = torch.device("cpu")
+
+            def apply_model(self, x, t, c):
+                return unet(torch.cat([x] + [c], dim=1), t) if concat else unet(x, t, context=c)
+        sm = DDIMSampler(Shim())
+        sm.device = torch.device("cpu")
+        return sm
+
+    out = dict(S=S, n_batch=n_batch, row_i2a=row_i2a, row_inp=row_inp)
+    with torch.no_grad():
+        r = row_i2a
+        u = unet_case("unet_i2a", C.UNET_I2A, 10, 78, 1, {}, seed=4, save=False)
+        z, _ = sampler_for(u, C.LDM_I2A).sample(S=S, conditioning=emb[r:r + 1], batch_size=1, shape=[4, 10, 78], verbose=False,
+                                                unconditional_guidance_scale=3.0, unconditional_conditioning=uc[:1],
+                                                x_T=xT_i2a[r:r + 1])
+        spec = torch.clamp((dec(pq(z)) + 1.0) / 2.0, 0.0, 1.0)[:, 0]
+        out.update(i2a_z=z.numpy(), i2a_spec=spec.numpy(), i2a_wav=gen(spec)[:, 0].numpy())
+        r = row_inp
+        u = unet_case("unet_inpaint", C.UNET_INPAINT, 10, 106, 0, {}, n=1, seed=5, save=False)
+        m, k = mel[r:r + 1], mask[r:r + 1]
+        mean, logvar = qc(enc((1 - k) * m * 2 - 1)).chunk(2, dim=1)                      # autoencoder.py:345-349
+        zc = mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise[r:r + 1]  # distributions.py:34-47
+        cc = torch.nn.functional.interpolate(k * 2 - 1, size=zc.shape[-2:])             # audio-chatgpt.py:510-511
+        c = torch.cat((zc, cc), dim=1)
+        z, _ = sampler_for(u, C.LDM_INPAINT).sample(S=S, conditioning=c, batch_size=1, shape=(4, 10, 106), verbose=False,
+                                                    x_T=xT_inp[r:r + 1])
+        pred = torch.clamp((dec(pq(z)) + 1.0) / 2.0, 0.0, 1.0)
+        comp = ((1 - k) * m + k * pred)[:, 0]                                            # (:523-526)
+        out.update(inp_z=z.numpy(), inp_spec=comp.numpy(), inp_wav=gen(comp)[:, 0].numpy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **{k: (v.astype(np.float32) if isinstance(v, np.ndarray) else v)
+                                                              for k, v in out.items()})
+    print(name, "i2a z std", float(out["i2a_z"].std()), "wav std", float(out["i2a_wav"].std()),
+          "| inpaint z std", float(out["inp_z"].std()), "wav std", float(out["inp_wav"].std()))
+
+
+def main_mixed_only():
+    """`python tests/golden/make_golden.py mixed`"""
+    torch.set_num_threads(8)
+    _install_shims()
+    mixed_case("mixed_config5_s100")
+    print("torch", torch.__version__)
+
+
 def main_clap_audio_only():
     """`python tests/golden/make_golden.py clapaudio`: the CLAP audio-branch case (groundwork, SURVEY 8f / N4 scorer)."""
     torch.set_num_threads(8)
@@ -847,4 +934,4 @@ def main_ddim_variants_only():
 
 if __name__ == "__main__":
     {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "diffsinger": main_diffsinger_only,
-     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only, "cliptext": main_clip_text_only, "clapaudio": main_clap_audio_only, "clapscore": main_clap_score_only}.get(" ".join(sys.argv[1:]), main)()
+     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only, "cliptext": main_clip_text_only, "clapaudio": main_clap_audio_only, "clapscore": main_clap_score_only, "mixed": main_mixed_only}.get(" ".join(sys.argv[1:]), main)()

@@ -88,6 +88,26 @@ def test_ddim_graph_replay_is_bit_identical(golden, unet_t2a):
     assert torch.equal(z0, z1)
 
 
+def test_ddim_step_graph_is_kept_across_calls_and_invalidated_by_its_inputs(golden, unet_t2a):
+    """The captured step outlives sample(): a second call with other latents / conditioning VALUES (in fresh buffers) replays
+    it and equals the eager loop; another guidance scale, batch or step count must not reuse it."""
+    g = golden("ddim_t2a_s10")
+    steps, a, ap = _ddim_tables(5, C.LDM_T2A)
+    c, uc, x = torch.from_numpy(g["c"]), torch.from_numpy(g["uc"]), torch.from_numpy(g["x_T"])
+    gen = torch.Generator().manual_seed(3)
+    cases = [dict(x=x, c=c, uc=uc, scale=1.5, st=(steps, a, ap)),
+             dict(x=torch.randn(x.shape, generator=gen), c=torch.randn(c.shape, generator=gen), uc=uc, scale=1.5, st=(steps, a, ap)),
+             dict(x=x, c=c, uc=uc, scale=2.5, st=(steps, a, ap)),                                  # other guidance scale
+             dict(x=x[:1], c=c[:1], uc=uc[:1], scale=2.5, st=(steps, a, ap)),                      # other batch
+             dict(x=x, c=c, uc=uc, scale=1.5, st=_ddim_tables(7, C.LDM_T2A)),                      # other step count
+             dict(x=x, c=c, uc=uc, scale=1.5, st=(steps, a, ap))]
+    for i, k in enumerate(cases):
+        kw = dict(cond=k["c"], uncond=k["uc"], scale=k["scale"])
+        zg = unet_t2a.ddim_sample(k["x"].clone(), *k["st"], use_graph=True, **kw).cpu()
+        ze = unet_t2a.ddim_sample(k["x"].clone(), *k["st"], use_graph=False, **kw).cpu()
+        assert torch.equal(zg, ze), "case %d: graph replay differs from the eager loop" % i
+
+
 def test_vae_decode_and_encode_match_reference(golden, vae):
     g = golden("vae")
     mel = vae.decode(torch.from_numpy(g["z"]), 1.0)

@@ -28,7 +28,8 @@ def test_hifigan_nsf_matches_reference(golden, precision):
     mel, f0 = torch.from_numpy(g["mel"]), torch.from_numpy(g["f0"])
     rand_ini, noise = N.draw_source_noise(int(g["noise_seed"]), mel.shape[0], mel.shape[2] * hop)
     ctx = Context("cuda:0", precision=precision)
-    v = Vocoder(ctx, cfg, WT.make_vocoder_state_dict(cfg, seed=6))
+    sd = WT.make_vocoder_state_dict(cfg, seed=6)
+    v = Vocoder(ctx, cfg, sd)
     wav = v(mel, f0, rand_ini=rand_ini, noise=noise).cpu()
     ref = torch.from_numpy(g["wav"])
     rms = float(((wav.double() - ref.double()) ** 2).mean().sqrt())
@@ -38,10 +39,11 @@ def test_hifigan_nsf_matches_reference(golden, precision):
     # batch rows are independent
     one = v(mel[1:2], f0[1:2], rand_ini=rand_ini[1:2], noise=noise[1:2]).cpu()
     assert torch.equal(one, wav[1:2])
-    # the plain entry point refuses a generator that needs f0, as the reference's forward would fail on f0=None sources
-    from audiogpt_amd._lib import MaaError
-    with pytest.raises(MaaError):
-        v.forward(mel)
+    # without f0 the generator skips its source branch (HifiGanGenerator.forward(x, f0=None), hifigan.py:144-169)
+    from oracle import vocoder as O_voc
+    with torch.no_grad():
+        plain = O_voc.hifigan_forward(O_voc.fold_weight_norm(sd), cfg, mel)
+    check(f"{precision}_hifigan_nsf_24k_called_without_f0_vs_oracle", v.forward(mel).cpu(), plain, 2e-4)
     v.close()
     ctx.close()
 
