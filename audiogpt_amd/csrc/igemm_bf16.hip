@@ -406,6 +406,26 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     }
     static const bool no_dma = std::getenv("MAA_NO_DMA") != nullptr;      // tests: same arithmetic, register staging
     const bool dma = terms == 3 && p.a_split && p.b_split && cfg != 3 && !no_dma;
+    const PPPlan planp = dma ? igemm_pp_plan(p) : PPPlan();
+    if (planp.bn) {
+        // halo-staged ping-pong engine for the 3x3 convolutions (igemm_pp.hip); slabs borrowed like the second engine's
+        const size_t mk = ctx.ws.mark();
+        const size_t nf = igemm_pp_workspace_floats(p, planp);
+        float* part = nf ? ctx.ws.alloc_f(nf) : nullptr;
+        if (!ctx.ws.dry) {
+            char shapep[64];
+            const char* namep = igemm_pp_name(planp);
+            if (ctx.prof && ctx.prof->detail) {
+                std::snprintf(shapep, sizeof(shapep), "pp%d M%d N%d K%d S%d", planp.bn, p.M, ncols, p.K, planp.S);
+                namep = shapep;
+            }
+            ProfScope profp(ctx, namep, 2.0 * p.M * (double)ncols * p.K, 4.0 * ((double)p.K * ncols + (double)p.M * p.N));
+            launch_igemm_pp(ctx, p, Nb, planp, part);
+            MAA_HIP(hipGetLastError());
+        }
+        ctx.ws.release(mk);
+        return true;
+    }
     const Dma2Plan plan2 = dma ? igemm_dma2_plan(p) : Dma2Plan();
     if (plan2.cfg >= 0) {
         // wide tiles + split-K; the slabs are borrowed from the arena for the duration of the two launches (stream order

@@ -432,17 +432,7 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTH), lds, ctx.stream, p, ntiles, tiles, Nb, cps, (int)items,
                        S > 1 ? part : nullptr);
-    if (S > 1) {
-        if constexpr (NI % 2 == 0) {
-            if (p.geglu) {
-                hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)(tiles * MI * (NI / 2))), dim3(NTH), 0, ctx.stream, p,
-                                   part, S, tiles, ntiles, Nb, BM, BN, WGN, MI, NI);
-                return;
-            }
-        }
-        hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)(tiles * MI * NI)), dim3(NTH), 0, ctx.stream, p, part, S, tiles,
-                           ntiles, Nb, BM, BN, WGN, MI, NI);
-    }
+    if (S > 1) launch_splitk_reduce(ctx, p, part, S, tiles, ntiles, Nb, BM, BN, WGN, MI, NI, NTH);
 }
 
 // slices for a K of `nchunks` 32-deep chunks such that no slice is empty: the largest S' <= S with
@@ -508,6 +498,18 @@ Dma2Plan plan_impl(const IGemm& p) {
 }
 
 }  // namespace
+
+void launch_splitk_reduce(const Ctx& ctx, const IGemm& p, const float* part, int S, int tiles, int ntiles, int Nb, int BM,
+                          int BN, int WGN, int MI, int NI, int NTH) {
+    if (p.geglu && NI % 2 == 0) {
+        hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)(tiles * MI * (NI / 2))), dim3(NTH), 0, ctx.stream, p, part, S,
+                           tiles, ntiles, Nb, BM, BN, WGN, MI, NI);
+        return;
+    }
+    MAA_CHECK(!p.geglu, "split-K reduce: GEGLU needs value / gate block pairs inside a wave");
+    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)(tiles * MI * NI)), dim3(NTH), 0, ctx.stream, p, part, S, tiles,
+                       ntiles, Nb, BM, BN, WGN, MI, NI);
+}
 
 Dma2Plan igemm_dma2_plan(const IGemm& p) { return plan_impl(p); }
 

@@ -1,0 +1,416 @@
+// bf16x3 implicit GEMM, third LDS-DMA engine: the UNet's 3x3 convolutions with a HALO-STAGED A operand and two wave groups
+// per workgroup that alternate between a matrix phase and a memory phase ("ping-pong").
+//
+// Why (DESIGN.md 3.2 / VERDICT r2 #1, #2).  The second engine (igemm_dma2.hip) runs its K loop over (tap, channel chunk) and
+// DMAs every A line nine times, once per tap; all of a workgroup's waves issue their copies, read their fragments and
+// multiply in the SAME phase between the same barriers, so a SIMD's matrix pipe idles whenever its single wave issues LDS-DMA
+// pieces (60-180 cycles each) or waits for fragments: 40 % MFMA-busy.  Here
+//   * the K loop is (channel chunk outer, 9 taps inner).  The input positions an M tile of 256 outputs can touch -- the flat
+//     range [m0 - W - 1, m0 + 255 + W + 1] of the channels-last activation -- are staged ONCE per 32-channel chunk
+//     (256 + 2 W + 2 split32 lines) and every tap reads them at a line offset ky W + kx; lanes whose tap falls outside the
+//     image (row / sample edges of the flat range) read a zero line instead.  A's LDS-DMA bytes per (chunk x 9 taps) drop
+//     from 9 x 32 KB to 42-52 KB and its fabric re-reads from 9x to ~1.6x; only the weights stream tap by tap.
+//   * a workgroup is 8 waves = two groups of four; group g owns rows [128 g, 128 g + 128) of the 256 x BN tile.  Every SIMD
+//     hosts one wave of each group (waves w and w + 4 share a SIMD).  Time is cut into ticks separated by s_barrier: in a
+//     tick one group multiplies chunk q out of registers (2 k-steps x 3 MI NI MFMAs, nothing else) while the other reads
+//     ITS fragments of the chunk it multiplies next and issues its share of the LDS-DMA pieces; then they swap.  The
+//     matrix pipe of a SIMD always has one wave feeding it and the partner's memory phase costs it nothing
+//     (MI355X_MICROARCH.md, "Two waves per SIMD": matrix beside memory is the complementary pairing).
+//
+// Tick t: group g reads chunk q at tick 2 q + g and multiplies it at tick 2 q + g + 1.  The weights of chunk q live in slot
+// q % 3 of a 3-slot ring and are needed during ticks 2 q .. 2 q + 1; the pieces of chunk q + 2 are issued into the slot chunk
+// q - 1 has left, half by group 0 at tick 2 q, half by group 1 at tick 2 q + 1, and every wave ends a memory phase with
+// s_waitcnt vmcnt(NP) -- everything but the NP pieces it has just issued has landed -- so a piece has two ticks (~1600
+// cycles) to arrive.  A is double-buffered by channel chunk: the pieces of chunk c + 1 are issued one per wave and memory
+// phase over taps 0..7 of chunk c.  Every wave issues exactly NP pieces per memory phase (pieces that do not exist copy the
+// zero page into a dump line) so the vmcnt arithmetic is the same constant everywhere.
+//
+// Numerical contract: per accumulator the products of a k-step are issued lo.hi, hi.lo, hi.hi like the other engines, but
+// the k-steps run (channel chunk, tap, k) instead of (tap, channel, k): results differ from the other engines in the last
+// bits; which engine a layer takes is a function of the layer (taps, W, C, N), never of M, and so is the number of K
+// slices -- a sample's result does not depend on its batch.
+#include "igemm_epilogue.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+namespace maa {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BK = 32;          // channels per chunk = one split32 line
+constexpr int BM = 256;         // output rows per workgroup
+constexpr int NSB = 3;          // weight ring
+constexpr int TAPS = 9;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct PPArgs {
+    int W, H;            // image width / height (stride 1, "same" padding: output = input geometry)
+    int NLp;             // A lines per buffer: 256 + 2 W + 2 rounded up to a multiple of 8
+    int ntiles, tiles;   // N tiles, M tiles x N tiles
+    int nci, cps;        // channel chunks in all, per K slice
+    int Nb;              // rows of the packed weight that exist
+    float* part;         // split-K slabs or null
+};
+
+// MI x NI fragments of 32x32 per wave; a group's 128 x BN block is GWM x GWN waves (GWM GWN = 4, GWM 32 MI = 128)
+template <int MI, int NI, int GWM, int GWN>
+__global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPArgs q) {
+    constexpr int BN = GWN * NI * 32;
+    constexpr int BPG = BN / 16;                    // weight pieces (8 rows x 128 B) per group and chunk: half a chunk
+    constexpr int NPB = (BPG + 3) / 4;              // ... per wave and memory phase
+    constexpr int NP = NPB + 1;                     // + one A piece
+    static_assert(GWM * GWN == 4 && GWM * MI * 32 == 128, "group geometry");
+    static_assert(BN % 16 == 0, "weight pieces");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    // [A buffer 0][A buffer 1][weight slot 0..2][zero line 128 B][dump 1 KB]
+    const int a_bytes = q.NLp * 128;
+    char* const sA = smem;
+    char* const sB = smem + 2 * a_bytes;
+    char* const sZ = sB + NSB * BN * 128;
+    char* const sD = sZ + 128;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, wq = wid & 3;
+    const int wm = wq / GWN, wn = wq - wm * GWN;
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    // ---- work item: (K slice, M tile, N tile), an XCD (block b runs on XCD b % 8) owns a contiguous range of items
+    int item;
+    {
+        const int items = (int)gridDim.x, xcd = blockIdx.x & 7, qq = items >> 3, rr = items & 7;
+        item = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (int)(blockIdx.x >> 3);
+    }
+    const int slice = item / q.tiles, tile = item - slice * q.tiles;
+    const int mt = tile / q.ntiles, nt = tile - mt * q.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int c_begin = slice * q.cps;
+    const int c_end = min(q.nci, c_begin + q.cps);
+    const int NQ = (c_end - c_begin) * TAPS;
+    const int W = q.W, H = q.H;
+    const long long Mtot = p.M;
+    const char* const zero = reinterpret_cast<const char*>(p.zeros);
+
+    // zero line (read by lanes whose tap is outside the image)
+    if (tid < 8) *reinterpret_cast<f32x4*>(sZ + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addressing
+    // A: row r of the tile sits at line r + ky W + kx of the buffer for tap (ky, kx); 16-byte slot s of line l is stored at
+    // slot s ^ ((l >> 1) & 7).  valid9: bit t set when tap t of this lane's row is inside the image.
+    int a_r[MI];
+    unsigned valid9[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        a_r[i] = grp * 128 + wm * (32 * MI) + i * 32 + lrow;
+        const long long m = (long long)m0 + a_r[i];
+        unsigned v = 0;
+        if (m < Mtot) {
+            const int ox = (int)(m % W), oy = (int)((m / W) % H);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v |= 1u << t;
+            }
+        }
+        valid9[i] = v;
+    }
+    const int lk16 = lk << 4;
+    const unsigned zaddr = (unsigned)(sZ - smem);
+    // B: row n of the slot at n * 128, slot swizzle by the row (tile offsets are multiples of 32 rows)
+    const int b_row = (wn * (32 * NI) + lrow) * 128;
+    const int b_swz = (lrow >> 1) & 7;
+    int b_off[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b_off[pl][ks] = b_row + (((pl * 4 + ks * 2 + lk) ^ b_swz) << 4);
+
+    // ---- copies.  Lane i of a piece moves the 16 bytes of slot (i & 7) ^ swizzle(line) of line 8 piece + (i >> 3).
+    const int r8 = lane >> 3, sl = lane & 7;
+    // weights: this wave's pieces of a chunk are pb = grp BPG + k 4 + wq (k < NPB, existing while k 4 + wq < BPG)
+    const char* gpb[NPB];
+#pragma unroll
+    for (int k = 0; k < NPB; ++k) {
+        const int pb = grp * BPG + k * 4 + wq;
+        const int nl = 8 * pb + r8;
+        const int n = min(n0 + nl, q.Nb - 1);          // rows past the last one: clamped, their columns are never stored
+        gpb[k] = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4);
+    }
+    const int C = p.C1;
+    auto b_chunk_off = [&](int ci, int t) __attribute__((always_inline)) { return ((long long)t * C + (long long)ci * BK) * 4; };
+    // issue this wave's weight pieces of chunk (ci, t) into ring slot `slot`; !live: dummies (zero page -> dump line)
+    auto issue_b = [&](int ci, int t, int slot, bool live) __attribute__((always_inline)) {
+        const long long off = b_chunk_off(ci, t);
+        static_for<0, NPB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const bool real = live && (k * 4 + wq < BPG);       // wave-uniform
+            const char* src = real ? gpb[k] + off : zero;
+            char* dst = real ? sB + slot * (BN * 128) + (grp * BPG + k * 4 + wq) * 1024 : sD;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        });
+    };
+    // A piece pa of channel chunk ci into buffer `buf`; pieces past the buffer or !live: dummy
+    const char* const a_base = reinterpret_cast<const char*>(p.a1);
+    auto issue_a = [&](int ci, int pa, int buf, bool live) __attribute__((always_inline)) {
+        const bool real = live && pa * 8 < q.NLp;                // wave-uniform
+        const int line = pa * 8 + r8;
+        const long long P = (long long)m0 - W - 1 + line;        // flat input position of this line
+        const bool inside = real && P >= 0 && P < Mtot;
+        const char* src = inside ? a_base + (P * p.lda1 + (long long)ci * BK) * 4 + ((sl ^ ((line >> 1) & 7)) << 4) : zero;
+        char* dst = real ? sA + buf * a_bytes + pa * 1024 : sD;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    };
+
+    // ---- prologue: A of the first chunk and the weights of chunks 0 and 1, by all eight waves
+    for (int pa = wid; pa * 8 < q.NLp; pa += 8) issue_a(c_begin, pa, 0, true);
+#pragma unroll
+    for (int j = 0; j < NSB - 1; ++j) {
+        // (an item has at least 9 chunks)
+        for (int pb = wid; pb < BN / 8; pb += 8) {
+            const int nl = 8 * pb + r8;
+            const int n = min(n0 + nl, q.Nb - 1);
+            const char* src = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4) +
+                              b_chunk_off(c_begin, j);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + j * (BN * 128) + pb * 1024), 16, 0, 0);
+        }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    bf16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];      // [k-step][fragment]
+
+    // memory phase of chunk j = (ci, t): fragments of the chunk into registers, this wave's pieces of chunk j + 2 and of
+    // the next channel chunk's A on their way
+    auto load_phase = [&](int j, int ci, int t, int slot) __attribute__((always_inline)) {
+        const char* const abuf = sA + ((ci - c_begin) & 1) * a_bytes;
+        const int shift = (t / 3) * W + (t % 3);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int line = a_r[i] + shift;
+            const int t1 = lk16 ^ (((line >> 1) & 7) << 4);
+            const unsigned base = (unsigned)(abuf - smem) + (unsigned)line * 128u;
+            const bool ok = (valid9[i] >> t) & 1u;
+            // [plane][k-step] -> slot plane 4 + ks 2 + lk
+            const unsigned a00 = ok ? base + (unsigned)(0x00 ^ t1) : zaddr;
+            const unsigned a01 = ok ? base + (unsigned)(0x20 ^ t1) : zaddr;
+            const unsigned a10 = ok ? base + (unsigned)(0x40 ^ t1) : zaddr;
+            const unsigned a11 = ok ? base + (unsigned)(0x60 ^ t1) : zaddr;
+            ah[0][i] = *reinterpret_cast<const bf16x8*>(smem + a00);
+            ah[1][i] = *reinterpret_cast<const bf16x8*>(smem + a01);
+            al[0][i] = *reinterpret_cast<const bf16x8*>(smem + a10);
+            al[1][i] = *reinterpret_cast<const bf16x8*>(smem + a11);
+        }
+        const char* const bs = sB + slot * (BN * 128);
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bh[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[0][ks]);
+                bl[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[1][ks]);
+            }
+        }
+        // chunk j + 2 -> the slot chunk j - 1 has left (both groups have read it: the barrier before this tick)
+        {
+            const int j2 = j + (NSB - 1);
+            int t2 = t + (NSB - 1), ci2 = ci;
+            if (t2 >= TAPS) {
+                t2 -= TAPS;
+                ++ci2;
+            }
+            int slot2 = slot + (NSB - 1);
+            if (slot2 >= NSB) slot2 -= NSB;
+            issue_b(ci2, t2, slot2, j2 < NQ);
+        }
+        // A of the next channel chunk: piece (t 2 + grp) 4 + wq during taps 0..7
+        issue_a(ci + 1, (t * 2 + grp) * 4 + wq, ((ci - c_begin) & 1) ^ 1, t < TAPS - 1 && ci + 1 < c_end);
+        wait_lgkm0();
+        wait_vmcnt<NP>();       // all but the NP pieces just issued have landed
+    };
+
+    auto mma_phase = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][jn], acc[i][jn], 0, 0, 0);
+        }
+    };
+
+    // ---- ticks.  Group 1 runs one tick behind group 0; every wave passes 2 NQ barriers.
+    if (grp == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    int ci = c_begin, t = 0, slot = 0;
+    for (int j = 0; j < NQ; ++j) {
+        load_phase(j, ci, t, slot);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(grp == 1 && j == NQ - 1)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (++t == TAPS) {
+            t = 0;
+            ++ci;
+        }
+        if (++slot == NSB) slot = 0;
+    }
+    wait_vmcnt<0>();        // (dummies only) nothing may land in LDS after the workgroup has given it back
+
+    // ---- epilogue or slab
+    const int rpb = p.Hout * p.Wout;
+    const int row_base = m0 + grp * 128 + wm * (32 * MI), col_base = n0 + wn * (32 * NI);
+    if (q.part == nullptr) {
+        igemm_epilogue<MI, NI>(p, acc, row_base, col_base, lrow, lk, 0, q.Nb, rpb);
+    } else {
+        // slab of this (slice, tile): [MI NI blocks][4 register quads][512 threads][4 floats]
+        float* pp = q.part + ((long long)item * (MI * NI * 4) * 512 + tid) * 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x4 v = {acc[i][jn][4 * qd], acc[i][jn][4 * qd + 1], acc[i][jn][4 * qd + 2], acc[i][jn][4 * qd + 3]};
+                    *reinterpret_cast<f32x4*>(pp + (long long)((i * NI + jn) * 4 + qd) * 512 * 4) = v;
+                }
+    }
+}
+
+template <int MI, int NI, int GWM, int GWN>
+void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part) {
+    constexpr int BN = GWN * NI * 32;
+    const int ncols = p.N;
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = (ncols + BN - 1) / BN;
+    PPArgs q;
+    q.W = p.Win;
+    q.H = p.Hin;
+    q.NLp = (BM + 2 * p.Win + 2 + 7) / 8 * 8;
+    q.ntiles = ntiles;
+    q.tiles = mtiles * ntiles;
+    q.nci = p.C1 / BK;
+    q.cps = (q.nci + pl.S - 1) / pl.S;
+    q.Nb = Nb;
+    q.part = pl.S > 1 ? part : nullptr;
+    MAA_CHECK((q.nci + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
+    const size_t lds = (size_t)2 * q.NLp * 128 + (size_t)NSB * BN * 128 + 128 + 1024;
+    MAA_CHECK(lds <= 163840, "igemm_pp: LDS per workgroup");
+    auto kern = igemm_pp_kernel<MI, NI, GWM, GWN>;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
+    const int items = q.tiles * pl.S;
+    hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
+    if (pl.S > 1) launch_splitk_reduce(ctx, p, part, pl.S, q.tiles, ntiles, Nb, BM, BN, GWN, MI, NI, 512);
+}
+
+}  // namespace
+
+// Which problems take this engine: 3x3, stride 1, "same" zero padding, one split32 source, split32 weights, a whole number of
+// 32-channel chunks, and an image narrow enough for two A buffers + the weight ring to fit the CU's LDS.  The tile width and
+// the number of K slices depend on the layer only (never on M).  MAA_PP = "off" | "bn,S" overrides (tuning and tests).
+PPPlan igemm_pp_plan(const IGemm& p) {
+    PPPlan pl;
+    if (!(p.KH == 3 && p.KW == 3 && p.sh == 1 && p.sw == 1 && p.dh == 1 && p.dw == 1 && p.ph == 1 && p.pw == 1 && p.up == 0))
+        return pl;
+    if (!(p.a_split && p.b_split && p.b_nk && p.C2 == 0 && p.C1 % BK == 0 && p.Z == 1 && p.a_act == 0 && !p.geglu)) return pl;
+    if (p.Hout != p.Hin || p.Wout != p.Win || p.K != 9 * p.C1 || p.N < 64) return pl;
+    const int NLp = (BM + 2 * p.Win + 2 + 7) / 8 * 8;
+    auto fits = [&](int bn) { return (size_t)2 * NLp * 128 + (size_t)NSB * bn * 128 + 1152 <= 163840; };
+    const int nci = p.C1 / BK;
+    int bn = 0, S = 0;
+    const char* env = std::getenv("MAA_PP");
+    if (env && *env) {
+        if (env[0] == 'o') return pl;
+        std::sscanf(env, "%d,%d", &bn, &S);
+    }
+    if (bn != 128 && bn != 160) {
+        // N a multiple of 160 but not of 128 (320): 160-wide tiles waste nothing; else 128
+        bn = (p.N % 160 == 0 && p.N % 128 != 0 && fits(160)) ? 160 : 128;
+    }
+    if (!fits(bn)) {
+        if (bn == 160 && fits(128))
+            bn = 128;
+        else
+            return pl;
+    }
+    if (S <= 0) {
+        // enough (slice, tile) items for one round of 256 workgroups at the UNet's two resolutions without the slab round
+        // trip outgrowing the contraction: N tiles x S ~ 13-16 per 256-row M tile
+        const int ntiles = (p.N + bn - 1) / bn;
+        S = ntiles >= 4 ? 3 : 2;
+    }
+    if (S > nci) S = nci;
+    for (; S > 1; --S) {
+        const int cps = (nci + S - 1) / S;
+        if ((nci + cps - 1) / cps == S) break;
+    }
+    pl.bn = bn;
+    pl.S = S < 1 ? 1 : S;
+    return pl;
+}
+
+size_t igemm_pp_workspace_floats(const IGemm& p, const PPPlan& pl) {
+    if (pl.bn == 0 || pl.S <= 1) return 0;
+    const long long tiles = (long long)((p.M + BM - 1) / BM) * ((p.N + pl.bn - 1) / pl.bn);
+    return (size_t)(tiles * pl.S * BM * pl.bn);
+}
+
+const char* igemm_pp_name(const PPPlan& pl) {
+    if (pl.bn == 160) return pl.S > 1 ? "igemm_pp_bf16x3<256x160,splitK>" : "igemm_pp_bf16x3<256x160>";
+    return pl.S > 1 ? "igemm_pp_bf16x3<256x128,splitK>" : "igemm_pp_bf16x3<256x128>";
+}
+
+void launch_igemm_pp(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part) {
+    MAA_CHECK(pl.bn == 128 || pl.bn == 160, "igemm_pp: problem not planned for this engine");
+    MAA_CHECK(pl.S == 1 || part != nullptr, "igemm_pp: split-K needs its slab workspace");
+    if (pl.bn == 128)
+        launch_one<2, 2, 2, 2>(ctx, p, Nb, pl, part);
+    else
+        launch_one<1, 5, 4, 1>(ctx, p, Nb, pl, part);
+}
+
+}  // namespace maa

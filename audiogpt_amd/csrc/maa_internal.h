@@ -186,6 +186,20 @@ size_t igemm_dma2_workspace_floats(const IGemm& p, const Dma2Plan& pl);      // 
 const char* igemm_dma2_name(const Dma2Plan& pl);
 void launch_igemm_dma2(const Ctx& ctx, const IGemm& p, int Nb, const Dma2Plan& pl, float* part);
 
+// adds the S slabs a split-K engine wrote in fragment order ([slice][tile][MI NI blocks][4 quads][NTH threads][4 floats]) in
+// slice order and applies the epilogue (igemm_dma2.hip); WGN / MI / NI / NTH describe the GEMM workgroup's wave geometry
+void launch_splitk_reduce(const Ctx& ctx, const IGemm& p, const float* part, int S, int tiles, int ntiles, int Nb, int BM,
+                          int BN, int WGN, int MI, int NI, int NTH);
+// third LDS-DMA engine (igemm_pp.hip): 3x3 convolutions with the A operand halo-staged once per channel chunk and two wave
+// groups alternating matrix / memory phases.  bn = 0: not taken.  Tile width and K slices depend on the layer only.
+struct PPPlan {
+    int bn = 0, S = 1;
+};
+PPPlan igemm_pp_plan(const IGemm& p);
+size_t igemm_pp_workspace_floats(const IGemm& p, const PPPlan& pl);
+const char* igemm_pp_name(const PPPlan& pl);
+void launch_igemm_pp(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part);
+
 // ------------------------------------------------------------------------------------------ norms etc.
 // GroupNorm(32 groups) over a channels-last tensor given as a virtual concat of two sources; writes
 // a dense [B, HW, C1+C2] tensor.  silu: fuse x*sigmoid(x).

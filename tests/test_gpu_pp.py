@@ -1,0 +1,119 @@
+"""The halo-staged ping-pong engine (csrc/igemm_pp.hip) at the operator level: 3x3 / stride 1 / "same" convolutions with the
+activation handed over pre-split (MAA_OP_PRESPLIT=1, the form GroupNorm writes inside the models), every (tile width, K
+slices) instantiation forced with MAA_PP, against torch.nn.functional.conv2d in fp32 on the CPU at the bf16x3 operator
+tolerance (rel-max 2e-4).  Plus the engine's contracts: repeated runs are bit-identical and a sample's rows do not depend on
+the batch they were computed in (the tile width and the number of K slices are functions of the layer only).
+"""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import check
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+VARIANTS = ["128,1", "128,2", "128,3", "128,5", "160,1", "160,2", "160,4"]      # tile width, K slices
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from audiogpt_amd.backend import Context
+    c = Context("cuda:0", precision="bf16x3")
+    yield c
+    c.close()
+
+
+class forced:
+    """Environment for one call: MAA_PP is read by the library when it plans a launch."""
+
+    def __init__(self, pp, presplit=True):
+        self.env = {"MAA_PP": pp, "MAA_OP_PRESPLIT": "1" if presplit else "0"}
+
+    def __enter__(self):
+        self.saved = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
+    def __exit__(self, *a):
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+CONVS = [  # B, Cin, Cout, H, W
+    (2, 320, 320, 10, 78),       # M = 1560: 6.1 tiles of 256, N = 2.5 / 2 tiles, 10 channel chunks
+    (3, 640, 640, 5, 39),        # a tile spans more than one sample (195 positions each): every edge mask in play
+    (1, 96, 200, 5, 39),         # M = 195 < one tile, N not a multiple of 32, 3 channel chunks (fewer than some slice counts)
+    (2, 64, 96, 7, 9),           # tiny image: the halo of a tile covers several samples
+    (1, 32, 64, 3, 100),         # widest image the two A buffers still fit (W = 100 with 128-wide tiles)
+]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("B,Cin,Cout,H,W", CONVS)
+def test_conv3x3(ctx, variant, B, Cin, Cout, H, W):
+    x = torch.randn(B, Cin, H, W, generator=g(7))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(8)) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g(9))
+    with forced(variant):
+        y = ctx.op_conv(x, w, b, pad=1)
+    check(f"pp[{variant}]_conv3x3_{Cin}_{Cout}_{H}x{W}_b{B}", y, F.conv2d(x, w, b, padding=1), TOL)
+
+
+def test_position_and_channel_probe(ctx):
+    """One-hot weights: output channel n copies input channel n of ONE tap -- a misplaced tap offset, edge mask, channel
+    chunk or weight row shows up as a wrong or shifted plane rather than as noise."""
+    B, C, H, W = 2, 64, 6, 11
+    x = torch.randn(B, C, H, W, generator=g(3))
+    for t in range(9):
+        w = torch.zeros(C, C, 3, 3)
+        w[torch.arange(C), torch.arange(C), t // 3, t % 3] = 1.0
+        for variant in ("128,1", "128,2"):
+            with forced(variant):
+                y = ctx.op_conv(x, w, None, pad=1)
+            ref = F.conv2d(x, w, None, padding=1)
+            assert (y.cpu() - ref).abs().max() < 1e-5, (t, variant, float((y.cpu() - ref).abs().max()))
+
+
+@pytest.mark.parametrize("variant", ["128,1", "128,3", "160,2", None])
+def test_deterministic_and_batch_invariant(ctx, variant):
+    """None = the default policy."""
+    x = torch.randn(6, 640, 5, 39, generator=g(21))
+    w = torch.randn(640, 640, 3, 3, generator=g(22)) / math.sqrt(5760)
+    b = torch.randn(640, generator=g(23))
+    with forced(variant if variant else ""):
+        y6 = ctx.op_conv(x, w, b, pad=1).cpu()
+        y6b = ctx.op_conv(x, w, b, pad=1).cpu()
+        y1 = ctx.op_conv(x[4:5], w, b, pad=1).cpu()
+    assert torch.equal(y6, y6b)
+    assert torch.equal(y6[4:5], y1)
+    check(f"pp[{variant}]_conv_640_b6", y6, F.conv2d(x, w, b, padding=1), TOL)
+
+
+def test_engine_is_selected_by_default_and_can_be_switched_off(ctx):
+    """The default policy takes the UNet's 3x3 convolutions; MAA_PP=off hands them back to the second engine -- both meet the
+    tolerance (they differ in the last bits: different order of the k-steps)."""
+    x = torch.randn(2, 320, 10, 78, generator=g(31))
+    w = torch.randn(320, 320, 3, 3, generator=g(32)) / math.sqrt(2880)
+    ref = F.conv2d(x, w, None, padding=1)
+    ctx.prof_begin(detail=True)
+    with forced(""):
+        y = ctx.op_conv(x, w, None, pad=1)
+    rows = ctx.prof_end()
+    assert any(k.startswith("pp") for k in rows), rows.keys()
+    ctx.prof_begin(detail=True)
+    with forced("off"):
+        y_off = ctx.op_conv(x, w, None, pad=1)
+    rows = ctx.prof_end()
+    assert not any(k.startswith("pp") for k in rows), rows.keys()
+    check("pp_default_conv_320", y, ref, TOL)
+    check("pp_off_conv_320", y_off, ref, TOL)
