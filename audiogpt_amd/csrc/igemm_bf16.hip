@@ -426,6 +426,25 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         ctx.ws.release(mk);
         return true;
     }
+    const PPPlan planq = dma && !planp.bn ? igemm_pp1_plan(p) : PPPlan();
+    if (planq.bn) {
+        const size_t mk = ctx.ws.mark();
+        const size_t nf = igemm_pp1_workspace_floats(p, planq);
+        float* part = nf ? ctx.ws.alloc_f(nf) : nullptr;
+        if (!ctx.ws.dry) {
+            char shapeq[64];
+            const char* nameq = igemm_pp1_name(planq);
+            if (ctx.prof && ctx.prof->detail) {
+                std::snprintf(shapeq, sizeof(shapeq), "pq%d M%d N%d K%d S%d", planq.bn, p.M, ncols, p.K, planq.S);
+                nameq = shapeq;
+            }
+            ProfScope profq(ctx, nameq, 2.0 * p.M * (double)ncols * p.K, 4.0 * ((double)p.K * ncols + (double)p.M * p.N));
+            launch_igemm_pp1(ctx, p, Nb, planq, part);
+            MAA_HIP(hipGetLastError());
+        }
+        ctx.ws.release(mk);
+        return true;
+    }
     const Dma2Plan plan2 = dma ? igemm_dma2_plan(p) : Dma2Plan();
     if (plan2.cfg >= 0) {
         // wide tiles + split-K; the slabs are borrowed from the arena for the duration of the two launches (stream order

@@ -71,10 +71,11 @@ struct PPArgs {
     int nci, cps;        // channel chunks in all, per K slice
     int Nb;              // rows of the packed weight that exist
     float* part;         // split-K slabs or null
+    int dbg;             // TUNE instantiation only (MAA_PP_DBG): 1 no MFMAs, 2 no copies after the prologue, 4 no fragment reads, 8 no waits
 };
 
 // MI x NI fragments of 32x32 per wave; a group's 128 x BN block is GWM x GWN waves (GWM GWN = 4, GWM 32 MI = 128)
-template <int MI, int NI, int GWM, int GWN>
+template <int MI, int NI, int GWM, int GWN, bool TUNE>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPArgs q) {
     constexpr int BN = GWN * NI * 32;
     constexpr int BPG = BN / 16;                    // weight pieces (8 rows x 128 B) per group and chunk: half a chunk
@@ -103,15 +104,15 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         const int items = (int)gridDim.x, xcd = blockIdx.x & 7, qq = items >> 3, rr = items & 7;
         item = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (int)(blockIdx.x >> 3);
     }
-    const int slice = item / q.tiles, tile = item - slice * q.tiles;
-    const int mt = tile / q.ntiles, nt = tile - mt * q.ntiles;
+    // (the quotients are wave-uniform but come out of the VALU's division sequence: back into SGPRs)
+    const int slice = __builtin_amdgcn_readfirstlane(item / q.tiles), tile = item - slice * q.tiles;
+    const int mt = __builtin_amdgcn_readfirstlane(tile / q.ntiles), nt = tile - mt * q.ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int c_begin = slice * q.cps;
     const int c_end = min(q.nci, c_begin + q.cps);
     const int NQ = (c_end - c_begin) * TAPS;
     const int W = q.W, H = q.H;
     const long long Mtot = p.M;
-    const char* const zero = reinterpret_cast<const char*>(p.zeros);
 
     // zero line (read by lanes whose tap is outside the image)
     if (tid < 8) *reinterpret_cast<f32x4*>(sZ + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -148,6 +149,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         for (int ks = 0; ks < 2; ++ks) b_off[pl][ks] = b_row + (((pl * 4 + ks * 2 + lk) ^ b_swz) << 4);
 
     // ---- copies.  Lane i of a piece moves the 16 bytes of slot (i & 7) ^ swizzle(line) of line 8 piece + (i >> 3).
+    // Every source address is valid memory whatever happens to its destination: weight rows and A positions are clamped
+    // (a clamped A line is only ever read by lanes whose tap is masked), pieces that do not exist land in the dump line.
     const int r8 = lane >> 3, sl = lane & 7;
     // weights: this wave's pieces of a chunk are pb = grp BPG + k 4 + wq (k < NPB, existing while k 4 + wq < BPG)
     const char* gpb[NPB];
@@ -158,33 +161,25 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         const int n = min(n0 + nl, q.Nb - 1);          // rows past the last one: clamped, their columns are never stored
         gpb[k] = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4);
     }
-    const int C = p.C1;
-    auto b_chunk_off = [&](int ci, int t) __attribute__((always_inline)) { return ((long long)t * C + (long long)ci * BK) * 4; };
-    // issue this wave's weight pieces of chunk (ci, t) into ring slot `slot`; !live: dummies (zero page -> dump line)
-    auto issue_b = [&](int ci, int t, int slot, bool live) __attribute__((always_inline)) {
-        const long long off = b_chunk_off(ci, t);
-        static_for<0, NPB>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            const bool real = live && (k * 4 + wq < BPG);       // wave-uniform
-            const char* src = real ? gpb[k] + off : zero;
-            char* dst = real ? sB + slot * (BN * 128) + (grp * BPG + k * 4 + wq) * 1024 : sD;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-        });
-    };
-    // A piece pa of channel chunk ci into buffer `buf`; pieces past the buffer or !live: dummy
+    const int C4 = p.C1 * 4;                           // bytes between the taps of a weight row
+    // A: during tap t of channel chunk c this wave issues piece (2 t + grp) 4 + wq of chunk c + 1: its lane's line advances
+    // by 64 per tap, the swizzle term (4 pa + (r8 >> 1)) & 7 only depends on wq's parity
     const char* const a_base = reinterpret_cast<const char*>(p.a1);
-    auto issue_a = [&](int ci, int pa, int buf, bool live) __attribute__((always_inline)) {
-        const bool real = live && pa * 8 < q.NLp;                // wave-uniform
+    const unsigned lda4 = (unsigned)p.lda1 * 4u;      // bytes between positions (< 2^31)
+    const int Mlast = p.M - 1;
+    const int a_P0 = m0 - W - 1 + 8 * (grp * 4 + wq) + r8;
+    const unsigned a_swz16 = (unsigned)((sl ^ (((r8 >> 1) + 4 * (wq & 1)) & 7)) << 4);
+    const int a_pieces = q.NLp >> 3;
+    // any piece (prologue)
+    auto issue_a_any = [&](int ci, int pa, int buf) __attribute__((always_inline)) {
         const int line = pa * 8 + r8;
-        const long long P = (long long)m0 - W - 1 + line;        // flat input position of this line
-        const bool inside = real && P >= 0 && P < Mtot;
-        const char* src = inside ? a_base + (P * p.lda1 + (long long)ci * BK) * 4 + ((sl ^ ((line >> 1) & 7)) << 4) : zero;
-        char* dst = real ? sA + buf * a_bytes + pa * 1024 : sD;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        const int P = min(max(m0 - W - 1 + line, 0), Mlast);
+        const char* src = a_base + ((unsigned long long)(unsigned)P * lda4 + (unsigned long long)ci * 128u) + ((sl ^ ((line >> 1) & 7)) << 4);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + buf * a_bytes + pa * 1024), 16, 0, 0);
     };
 
     // ---- prologue: A of the first chunk and the weights of chunks 0 and 1, by all eight waves
-    for (int pa = wid; pa * 8 < q.NLp; pa += 8) issue_a(c_begin, pa, 0, true);
+    for (int pa = wid; pa < a_pieces; pa += 8) issue_a_any(c_begin, pa, 0);
 #pragma unroll
     for (int j = 0; j < NSB - 1; ++j) {
         // (an item has at least 9 chunks)
@@ -192,7 +187,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
             const int nl = 8 * pb + r8;
             const int n = min(n0 + nl, q.Nb - 1);
             const char* src = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4) +
-                              b_chunk_off(c_begin, j);
+                              ((long long)j * C4 + (long long)c_begin * 128);
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + j * (BN * 128) + pb * 1024), 16, 0, 0);
         }
     }
@@ -209,52 +204,79 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
 
     bf16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];      // [k-step][fragment]
 
+    // loop state (all wave-uniform): the chunk being read is (ci, t) in ring slot `slot`, its tap offset in lines `shift`;
+    // the chunk whose weights are issued is two ahead: byte offset boff2 in a weight row, slot slot2, live while j + 2 < NQ
+    int ci = c_begin, t = 0, kx = 0, shift = 0, slot = 0;
+    int slot2 = NSB - 1, t2 = NSB - 1;
+    long long boff2 = (long long)(NSB - 1) * C4 + (long long)c_begin * 128;
+
     // memory phase of chunk j = (ci, t): fragments of the chunk into registers, this wave's pieces of chunk j + 2 and of
     // the next channel chunk's A on their way
-    auto load_phase = [&](int j, int ci, int t, int slot) __attribute__((always_inline)) {
-        const char* const abuf = sA + ((ci - c_begin) & 1) * a_bytes;
-        const int shift = (t / 3) * W + (t % 3);
+    auto load_phase = [&](int j) __attribute__((always_inline)) {
+        const unsigned abuf = (unsigned)(((ci - c_begin) & 1) * a_bytes);
+        if (!TUNE || !(q.dbg & 4)) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int line = a_r[i] + shift;
-            const int t1 = lk16 ^ (((line >> 1) & 7) << 4);
-            const unsigned base = (unsigned)(abuf - smem) + (unsigned)line * 128u;
-            const bool ok = (valid9[i] >> t) & 1u;
-            // [plane][k-step] -> slot plane 4 + ks 2 + lk
-            const unsigned a00 = ok ? base + (unsigned)(0x00 ^ t1) : zaddr;
-            const unsigned a01 = ok ? base + (unsigned)(0x20 ^ t1) : zaddr;
-            const unsigned a10 = ok ? base + (unsigned)(0x40 ^ t1) : zaddr;
-            const unsigned a11 = ok ? base + (unsigned)(0x60 ^ t1) : zaddr;
-            ah[0][i] = *reinterpret_cast<const bf16x8*>(smem + a00);
-            ah[1][i] = *reinterpret_cast<const bf16x8*>(smem + a01);
-            al[0][i] = *reinterpret_cast<const bf16x8*>(smem + a10);
-            al[1][i] = *reinterpret_cast<const bf16x8*>(smem + a11);
-        }
-        const char* const bs = sB + slot * (BN * 128);
+            for (int i = 0; i < MI; ++i) {
+                const int line = a_r[i] + shift;
+                const unsigned t1 = (unsigned)lk16 ^ (((unsigned)line << 3) & 0x70u);      // lk slot bit ^ swizzle((line >> 1) & 7)
+                const bool ok = (valid9[i] >> t) & 1u;
+                // a masked lane reads the zero line: its four 16-byte pieces at zaddr + (0 .. 0x70) are all inside it
+                const unsigned base = ok ? abuf + (unsigned)line * 128u : zaddr;
+                ah[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x00u ^ t1)));
+                ah[1][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x20u ^ t1)));
+                al[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x40u ^ t1)));
+                al[1][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x60u ^ t1)));
+            }
+            const char* const bs = sB + slot * (BN * 128);
 #pragma unroll
-        for (int jn = 0; jn < NI; ++jn) {
+            for (int jn = 0; jn < NI; ++jn) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bh[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[0][ks]);
-                bl[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[1][ks]);
+                for (int ks = 0; ks < 2; ++ks) {
+                    bh[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[0][ks]);
+                    bl[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[1][ks]);
+                }
             }
         }
-        // chunk j + 2 -> the slot chunk j - 1 has left (both groups have read it: the barrier before this tick)
-        {
-            const int j2 = j + (NSB - 1);
-            int t2 = t + (NSB - 1), ci2 = ci;
-            if (t2 >= TAPS) {
-                t2 -= TAPS;
-                ++ci2;
-            }
-            int slot2 = slot + (NSB - 1);
-            if (slot2 >= NSB) slot2 -= NSB;
-            issue_b(ci2, t2, slot2, j2 < NQ);
+        if (!TUNE || !(q.dbg & 2)) {
+            // weights of chunk j + 2 -> the slot chunk j - 1 has left (both groups have read it: the barrier before this tick)
+            const bool live = j + (NSB - 1) < NQ;
+            static_for<0, NPB>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                const bool real = live && (k * 4 + wq < BPG);       // wave-uniform
+                char* dst = real ? sB + slot2 * (BN * 128) + (grp * BPG + k * 4 + wq) * 1024 : sD;
+                __builtin_amdgcn_global_load_lds((gptr_t)(gpb[k] + boff2), (lptr_t)dst, 16, 0, 0);
+            });
+            // A of the next channel chunk: piece (2 t + grp) 4 + wq during taps 0..7
+            const int pa = (t * 2 + grp) * 4 + wq;
+            const bool real = t < TAPS - 1 && ci + 1 < c_end && pa < a_pieces;
+            const int P = min(max(a_P0 + 64 * t, 0), Mlast);
+            const char* src = a_base + ((unsigned long long)(ci + 1) * 128u) + ((unsigned long long)(unsigned)P * lda4 + a_swz16);
+            char* dst = real ? sA + (abuf ^ (unsigned)a_bytes) + pa * 1024 : sD;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
         }
-        // A of the next channel chunk: piece (t 2 + grp) 4 + wq during taps 0..7
-        issue_a(ci + 1, (t * 2 + grp) * 4 + wq, ((ci - c_begin) & 1) ^ 1, t < TAPS - 1 && ci + 1 < c_end);
-        wait_lgkm0();
-        wait_vmcnt<NP>();       // all but the NP pieces just issued have landed
+        if (!TUNE || !(q.dbg & 8)) {
+            wait_lgkm0();
+            wait_vmcnt<NP>();       // all but the NP pieces just issued have landed
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++shift;
+        if (++kx == 3) {
+            kx = 0;
+            shift += W - 3;
+        }
+        if (++t == TAPS) {
+            t = 0;
+            shift = 0;
+            ++ci;
+        }
+        if (++slot == NSB) slot = 0;
+        if (++slot2 == NSB) slot2 = 0;
+        boff2 += C4;
+        if (++t2 == TAPS) {
+            t2 = 0;
+            boff2 += 128 - (long long)TAPS * C4;
+        }
     };
 
     auto mma_phase = [&]() __attribute__((always_inline)) {
@@ -284,21 +306,16 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
-    int ci = c_begin, t = 0, slot = 0;
     for (int j = 0; j < NQ; ++j) {
-        load_phase(j, ci, t, slot);
+        load_phase(j);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mma_phase();
+        if (!TUNE || !(q.dbg & 1)) mma_phase();
         __builtin_amdgcn_sched_barrier(0);
         if (!(grp == 1 && j == NQ - 1)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (++t == TAPS) {
-            t = 0;
-            ++ci;
-        }
-        if (++slot == NSB) slot = 0;
+        advance();
     }
     wait_vmcnt<0>();        // (dummies only) nothing may land in LDS after the workgroup has given it back
 
@@ -340,13 +357,229 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     MAA_CHECK((q.nci + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
     const size_t lds = (size_t)2 * q.NLp * 128 + (size_t)NSB * BN * 128 + 128 + 1024;
     MAA_CHECK(lds <= 163840, "igemm_pp: LDS per workgroup");
-    auto kern = igemm_pp_kernel<MI, NI, GWM, GWN>;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
+    const int items = q.tiles * pl.S;
+    q.dbg = 0;
+    if (const char* e = std::getenv("MAA_PP_DBG")) {      // timing ablations: a separate instantiation, never the product's
+        q.dbg = std::atoi(e);
+        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, true>;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
+        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
+    } else {
+        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, false>;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
+        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
+    }
+    if (pl.S > 1) launch_splitk_reduce(ctx, p, part, pl.S, q.tiles, ntiles, Nb, BM, BN, GWN, MI, NI, 512);
+}
+
+
+// ------------------------------------------------------------------------------------------ 1x1 / Linear
+// The same two-group schedule for plain row-major contractions (q/k/v, to_out, proj_in/out, the GEGLU projection, ff.net.2):
+// no halo -- a chunk's A tile is its 256 rows' lines -- so A and the weights share one 3-slot ring [256 + BN lines] and a
+// wave issues NP1 = 4 + NPB pieces per memory phase.  Products are issued per accumulator in the order of the other engines
+// (k ascending; lo.hi, hi.lo, hi.hi per k-step): without a K split the result is bit-identical to theirs, with S slices to
+// the second engine's S-slice result.
+struct PP1Args {
+    int ntiles, tiles;   // N tiles, M tiles x N tiles
+    int nchunks, cps;    // 32-deep chunks in all, per K slice
+    int Nb;
+    float* part;
+};
+
+template <int MI, int NI, int GWM, int GWN>
+__global__ __launch_bounds__(512) void igemm_pp1_kernel(const IGemm p, const PP1Args q) {
+    constexpr int BN = GWN * NI * 32;
+    constexpr int BPG = BN / 16;                    // weight pieces per group and chunk
+    constexpr int NPB = (BPG + 3) / 4;
+    constexpr int NPA = 4;                          // A pieces per wave and memory phase: 16 per group
+    constexpr int NP = NPA + NPB;
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(GWM * GWN == 4 && GWM * MI * 32 == 128, "group geometry");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [3][A 256 lines | B BN lines][dump 1 KB]
+    char* const sD = smem + NSB * STAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, wq = wid & 3;
+    const int wm = wq / GWN, wn = wq - wm * GWN;
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    int item;
+    {
+        const int items = (int)gridDim.x, xcd = blockIdx.x & 7, qq = items >> 3, rr = items & 7;
+        item = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (int)(blockIdx.x >> 3);
+    }
+    const int slice = __builtin_amdgcn_readfirstlane(item / q.tiles), tile = item - slice * q.tiles;
+    const int mt = __builtin_amdgcn_readfirstlane(tile / q.ntiles), nt = tile - mt * q.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int c_begin = slice * q.cps;
+    const int NQ = min(q.nchunks, c_begin + q.cps) - c_begin;
+    const char* const zero = reinterpret_cast<const char*>(p.zeros);
+
+    // fragment offsets inside a stage (tile offsets are multiples of 32 rows: the swizzle depends on lrow only)
+    const int swz = (lrow >> 1) & 7;
+    const int a_row = (grp * 128 + wm * (32 * MI) + lrow) * 128, b_row = (BM + wn * (32 * NI) + lrow) * 128;
+    int s_off[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) s_off[pl][ks] = ((pl * 4 + ks * 2 + lk) ^ swz) << 4;
+
+    // copies: piece = 8 rows x 128 B; this wave's pieces of a chunk are A rows 8 (grp 16 + k 4 + wq) .. and weight rows
+    // 8 (grp BPG + k 4 + wq) ..; running per-lane source pointers, one 128-byte step per chunk
+    const int r8 = lane >> 3, sl = lane & 7;
+    const char* gpa[NPA];
+    const char* gpb[NPB];
+#pragma unroll
+    for (int k = 0; k < NPA; ++k) {
+        const int rl = 8 * (grp * 16 + k * 4 + wq) + r8;
+        const long long m = min((long long)m0 + rl, (long long)p.M - 1);      // rows past the last one: clamped, never stored
+        gpa[k] = reinterpret_cast<const char*>(p.a1) + (m * p.lda1 + (long long)c_begin * BK) * 4 + ((sl ^ ((rl >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NPB; ++k) {
+        const int nl = 8 * (grp * BPG + k * 4 + wq) + r8;
+        const int n = min(n0 + nl, q.Nb - 1);
+        gpb[k] = reinterpret_cast<const char*>(p.b) + ((long long)n * p.ldb + (long long)c_begin * BK) * 4 + ((sl ^ ((nl >> 1) & 7)) << 4);
+    }
+    // this wave's pieces of the chunk `ahead` chunks after the one its pointers stand at (ahead is 0 in steady state)
+    auto issue = [&](int slot, bool live) __attribute__((always_inline)) {
+        char* const st = smem + slot * STAGE;
+        static_for<0, NPA>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const char* src = live ? gpa[k] : zero;
+            char* dst = live ? st + (grp * 16 + k * 4 + wq) * 1024 : sD;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            gpa[k] += 128;
+        });
+        static_for<0, NPB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const bool real = live && (k * 4 + wq < BPG);       // wave-uniform
+            const char* src = real ? gpb[k] : zero;
+            char* dst = real ? st + BM * 128 + (grp * BPG + k * 4 + wq) * 1024 : sD;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            gpb[k] += 128;
+        });
+    };
+
+    // prologue: chunks 0 and 1 (each wave its own pieces of both), then everything landed
+    issue(0, true);
+    issue(1, NQ > 1);
+    wait_vmcnt<0>();
+    __syncthreads();
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+
+    auto load_phase = [&](int j, int slot) __attribute__((always_inline)) {
+        const char* const st = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                ah[ks][i] = *reinterpret_cast<const bf16x8*>(st + a_row + i * 4096 + s_off[0][ks]);
+                al[ks][i] = *reinterpret_cast<const bf16x8*>(st + a_row + i * 4096 + s_off[1][ks]);
+            }
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bh[ks][jn] = *reinterpret_cast<const bf16x8*>(st + b_row + jn * 4096 + s_off[0][ks]);
+                bl[ks][jn] = *reinterpret_cast<const bf16x8*>(st + b_row + jn * 4096 + s_off[1][ks]);
+            }
+        int slot2 = slot + (NSB - 1);
+        if (slot2 >= NSB) slot2 -= NSB;
+        issue(slot2, j + (NSB - 1) < NQ);       // chunk j + 2 -> the slot chunk j - 1 has left
+        wait_lgkm0();
+        wait_vmcnt<NP>();
+    };
+    auto mma_phase = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][jn], acc[i][jn], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][jn], acc[i][jn], 0, 0, 0);
+        }
+    };
+
+    if (grp == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    int slot = 0;
+    for (int j = 0; j < NQ; ++j) {
+        load_phase(j, slot);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mma_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(grp == 1 && j == NQ - 1)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (++slot == NSB) slot = 0;
+    }
+    wait_vmcnt<0>();
+
+    const int rpb = p.Hout * p.Wout;
+    const int row_base = m0 + grp * 128 + wm * (32 * MI), col_base = n0 + wn * (32 * NI);
+    if (q.part == nullptr) {
+        igemm_epilogue<MI, NI>(p, acc, row_base, col_base, lrow, lk, 0, q.Nb, rpb);
+    } else {
+        float* pp = q.part + ((long long)item * (MI * NI * 4) * 512 + tid) * 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const f32x4 v = {acc[i][jn][4 * qd], acc[i][jn][4 * qd + 1], acc[i][jn][4 * qd + 2], acc[i][jn][4 * qd + 3]};
+                    *reinterpret_cast<f32x4*>(pp + (long long)((i * NI + jn) * 4 + qd) * 512 * 4) = v;
+                }
+    }
+}
+
+template <int MI, int NI, int GWM, int GWN>
+void launch_one1(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part) {
+    constexpr int BN = GWN * NI * 32;
+    const int ncols = p.N * (p.geglu ? 2 : 1);
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = (ncols + BN - 1) / BN;
+    PP1Args q;
+    q.ntiles = ntiles;
+    q.tiles = mtiles * ntiles;
+    q.nchunks = p.K / BK;
+    q.cps = (q.nchunks + pl.S - 1) / pl.S;
+    q.Nb = Nb;
+    q.part = pl.S > 1 ? part : nullptr;
+    MAA_CHECK((q.nchunks + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
+    MAA_CHECK(!p.geglu || NI % 2 == 0, "GEGLU needs value / gate block pairs inside a wave");
+    constexpr size_t lds = (size_t)NSB * (BM + BN) * 128 + 1024;
+    static_assert(lds <= 163840, "LDS per workgroup");
+    auto kern = igemm_pp1_kernel<MI, NI, GWM, GWN>;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     const int items = q.tiles * pl.S;
     hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
     if (pl.S > 1) launch_splitk_reduce(ctx, p, part, pl.S, q.tiles, ntiles, Nb, BM, BN, GWN, MI, NI, 512);
 }
-
 }  // namespace
 
 // Which problems take this engine: 3x3, stride 1, "same" zero padding, one split32 source, split32 weights, a whole number of
@@ -411,6 +644,61 @@ void launch_igemm_pp(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, f
         launch_one<2, 2, 2, 2>(ctx, p, Nb, pl, part);
     else
         launch_one<1, 5, 4, 1>(ctx, p, Nb, pl, part);
+}
+
+
+// 1x1 / Linear problems (both operands split32, one source, a whole number of 32-deep chunks).  Without a K split the engine
+// is bit-identical to the others, so taking it may depend on M: only when the 256-row tiles fill a useful part of the chip.
+// The number of K slices follows the second engine's layer-only rule (K >= 2048: two slices).  MAA_PP1 = "off" | "bn,S".
+PPPlan igemm_pp1_plan(const IGemm& p) {
+    PPPlan pl;
+    if (!(p.KH == 1 && p.KW == 1 && p.a_split && p.b_split && p.b_nk && p.C2 == 0 && p.Z == 1 && p.a_act == 0 && p.up == 0)) return pl;
+    if (p.K % BK != 0 || p.K != p.C1 || p.K < 64) return pl;
+    const int ncols = p.N * (p.geglu ? 2 : 1);
+    int bn = 0, S = 0;
+    const char* env = std::getenv("MAA_PP1");
+    if (env && *env) {
+        if (env[0] == 'o') return pl;
+        std::sscanf(env, "%d,%d", &bn, &S);
+    }
+    const bool forced = bn == 128 || bn == 160;
+    if (!forced) {
+        bn = (!p.geglu && ncols % 160 == 0 && ncols % 128 != 0) ? 160 : 128;
+        const long long tiles = (long long)((p.M + BM - 1) / BM) * ((ncols + bn - 1) / bn);
+        if (ncols < 128 || tiles < 96) return pl;       // too few 256-row tiles: the smaller-tile engines fill the chip better
+    }
+    if (p.geglu) bn = 128;
+    const int nchunks = p.K / BK;
+    if (S <= 0) S = (p.K >= 2048 && !p.geglu) ? 2 : 1;
+    if (S > nchunks) S = nchunks;
+    for (; S > 1; --S) {
+        const int cps = (nchunks + S - 1) / S;
+        if ((nchunks + cps - 1) / cps == S) break;
+    }
+    pl.bn = bn;
+    pl.S = S < 1 ? 1 : S;
+    return pl;
+}
+
+size_t igemm_pp1_workspace_floats(const IGemm& p, const PPPlan& pl) {
+    if (pl.bn == 0 || pl.S <= 1) return 0;
+    const int ncols = p.N * (p.geglu ? 2 : 1);
+    const long long tiles = (long long)((p.M + BM - 1) / BM) * ((ncols + pl.bn - 1) / pl.bn);
+    return (size_t)(tiles * pl.S * BM * pl.bn);
+}
+
+const char* igemm_pp1_name(const PPPlan& pl) {
+    if (pl.bn == 160) return pl.S > 1 ? "igemm_pp1_bf16x3<256x160,splitK>" : "igemm_pp1_bf16x3<256x160>";
+    return pl.S > 1 ? "igemm_pp1_bf16x3<256x128,splitK>" : "igemm_pp1_bf16x3<256x128>";
+}
+
+void launch_igemm_pp1(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part) {
+    MAA_CHECK(pl.bn == 128 || pl.bn == 160, "igemm_pp1: problem not planned for this engine");
+    MAA_CHECK(pl.S == 1 || part != nullptr, "igemm_pp1: split-K needs its slab workspace");
+    if (pl.bn == 128)
+        launch_one1<2, 2, 2, 2>(ctx, p, Nb, pl, part);
+    else
+        launch_one1<1, 5, 4, 1>(ctx, p, Nb, pl, part);
 }
 
 }  // namespace maa

@@ -199,6 +199,11 @@ PPPlan igemm_pp_plan(const IGemm& p);
 size_t igemm_pp_workspace_floats(const IGemm& p, const PPPlan& pl);
 const char* igemm_pp_name(const PPPlan& pl);
 void launch_igemm_pp(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part);
+// ... and its 1x1 / Linear form (no halo; A and the weights share one ring)
+PPPlan igemm_pp1_plan(const IGemm& p);
+size_t igemm_pp1_workspace_floats(const IGemm& p, const PPPlan& pl);
+const char* igemm_pp1_name(const PPPlan& pl);
+void launch_igemm_pp1(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part);
 
 // ------------------------------------------------------------------------------------------ norms etc.
 // GroupNorm(32 groups) over a channels-last tensor given as a virtual concat of two sources; writes
