@@ -67,11 +67,11 @@ __global__ __launch_bounds__(NT) void flash_attn_kernel(const FlashArgs a) {
     constexpr int KS = DK / 16, MB = DM / 32;
     constexpr int PL = TERMS == 1 ? 1 : 2;
     constexpr int LDKK = DK + 8;                 // bf16 per K-tile row
-    constexpr int LDV = KT + 8;                  // bf16 per V^T row
+    constexpr int LDV = KT + 4;                  // bf16 per V^T row: 72 bytes -- the 32 rows a ds_read_b64 group touches start in
+                                                 // 32 different even banks (80-byte rows collide two by two)
     constexpr int K_PLANE = KT * LDKK, V_PLANE = DM * LDV;
     constexpr int BUF = PL * (K_PLANE + V_PLANE);            // bf16 elements of one K/V buffer
     constexpr int C4 = DH / 4;                               // float4 per K / V row
-    constexpr int NLD = (KT * C4 + NT - 1) / NT;             // float4 per thread per tile and operand
     static_assert(DH % 8 == 0, "head dim");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem[];   // [2][BUF]; reused for the O transpose
 
@@ -112,62 +112,59 @@ __global__ __launch_bounds__(NT) void flash_attn_kernel(const FlashArgs a) {
         }
     }
 
-    // ---- K / V tile staging (all 256 threads): element idx = tid + 256 j -> (key, 4 d)
-    float4 rk[NLD], rv[NLD];
+    // ---- K / V tile staging: thread (kb, c4) = (tid / C4, tid % C4) owns the 4 keys x 4 d block kb, c4 of both operands.
+    // K goes to LDS row by row; V is transposed in the registers it was loaded into -- component i of the four keys packs into
+    // two words -- so V^T[d][4 keys] is ONE 8-byte store per d (the 2-byte scattered stores this replaces were 5-way bank
+    // conflicts: 54 % of the kernel's LDS cycles, profiles/r2_pmc_sq_counters_dma2_first_policy.txt)
+    static_assert((KT / 4) * C4 <= NT, "one 4x4 block per thread");
+    const bool stager = tid < (KT / 4) * C4;
+    const int s_kb = tid / C4, s_c4 = tid - s_kb * C4;
+    float4 rk[4], rv[4];
     auto load_tile = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int idx = tid + NT * j;
-            const int key = idx / C4, c4 = idx - key * C4;
-            const int kg = kt * KT + key;
-            const bool ok = idx < KT * C4 && kg < a.Nk;
+        for (int j = 0; j < 4; ++j) {
+            const int kg = kt * KT + s_kb * 4 + j;
+            const bool ok = stager && kg < a.Nk;
             const long long row = ok ? kg : 0;
-            const float4 x = *(ok ? reinterpret_cast<const float4*>(kp + row * a.ldk + c4 * 4) : zero4);
-            const float4 y = *(ok ? reinterpret_cast<const float4*>(vp + row * a.ldv + c4 * 4) : zero4);
-            rk[j] = x;
-            rv[j] = y;
+            rk[j] = *(ok ? reinterpret_cast<const float4*>(kp + row * a.ldk + s_c4 * 4) : zero4);
+            rv[j] = *(ok ? reinterpret_cast<const float4*>(vp + row * a.ldv + s_c4 * 4) : zero4);
         }
     };
     auto store_tile = [&](int buf) {
+        if (!stager) return;
         unsigned short* base = smem + buf * BUF;
         unsigned short* vt = base + PL * K_PLANE;
 #pragma unroll
-        for (int j = 0; j < NLD; ++j) {
-            const int idx = tid + NT * j;
-            if (idx < KT * C4) {
-                const int key = idx / C4, c4 = idx - key * C4;
-                uint2 hi, lo;
-                if constexpr (TERMS == 1) {
-                    hi.x = pk_bf16(rk[j].x, rk[j].y);
-                    hi.y = pk_bf16(rk[j].z, rk[j].w);
-                } else {
-                    split2(rk[j].x, rk[j].y, hi.x, lo.x);
-                    split2(rk[j].z, rk[j].w, hi.y, lo.y);
-                    *reinterpret_cast<uint2*>(base + K_PLANE + key * LDKK + c4 * 4) = lo;
-                }
-                *reinterpret_cast<uint2*>(base + key * LDKK + c4 * 4) = hi;
-                // V transposed: V^T[d][key]
-                unsigned vh0, vh1, vl0 = 0, vl1 = 0;
-                if constexpr (TERMS == 1) {
-                    vh0 = pk_bf16(rv[j].x, rv[j].y);
-                    vh1 = pk_bf16(rv[j].z, rv[j].w);
-                } else {
-                    split2(rv[j].x, rv[j].y, vh0, vl0);
-                    split2(rv[j].z, rv[j].w, vh1, vl1);
-                }
-                const int d = c4 * 4;
-                vt[(d + 0) * LDV + key] = (unsigned short)(vh0 & 0xffffu);
-                vt[(d + 1) * LDV + key] = (unsigned short)(vh0 >> 16);
-                vt[(d + 2) * LDV + key] = (unsigned short)(vh1 & 0xffffu);
-                vt[(d + 3) * LDV + key] = (unsigned short)(vh1 >> 16);
-                if constexpr (TERMS == 3) {
-                    vt[V_PLANE + (d + 0) * LDV + key] = (unsigned short)(vl0 & 0xffffu);
-                    vt[V_PLANE + (d + 1) * LDV + key] = (unsigned short)(vl0 >> 16);
-                    vt[V_PLANE + (d + 2) * LDV + key] = (unsigned short)(vl1 & 0xffffu);
-                    vt[V_PLANE + (d + 3) * LDV + key] = (unsigned short)(vl1 >> 16);
-                }
+        for (int j = 0; j < 4; ++j) {
+            const int key = s_kb * 4 + j;
+            uint2 hi, lo;
+            if constexpr (TERMS == 1) {
+                hi.x = pk_bf16(rk[j].x, rk[j].y);
+                hi.y = pk_bf16(rk[j].z, rk[j].w);
+            } else {
+                split2(rk[j].x, rk[j].y, hi.x, lo.x);
+                split2(rk[j].z, rk[j].w, hi.y, lo.y);
+                *reinterpret_cast<uint2*>(base + K_PLANE + key * LDKK + s_c4 * 4) = lo;
             }
+            *reinterpret_cast<uint2*>(base + key * LDKK + s_c4 * 4) = hi;
         }
+        // V^T[d = 4 c4 + i][keys 4 kb .. 4 kb + 3]
+        auto put = [&](int i, float v0, float v1, float v2, float v3) {
+            uint2 hi, lo;
+            if constexpr (TERMS == 1) {
+                hi.x = pk_bf16(v0, v1);
+                hi.y = pk_bf16(v2, v3);
+            } else {
+                split2(v0, v1, hi.x, lo.x);
+                split2(v2, v3, hi.y, lo.y);
+                *reinterpret_cast<uint2*>(vt + V_PLANE + (s_c4 * 4 + i) * LDV + s_kb * 4) = lo;
+            }
+            *reinterpret_cast<uint2*>(vt + (s_c4 * 4 + i) * LDV + s_kb * 4) = hi;
+        };
+        put(0, rv[0].x, rv[1].x, rv[2].x, rv[3].x);
+        put(1, rv[0].y, rv[1].y, rv[2].y, rv[3].y);
+        put(2, rv[0].z, rv[1].z, rv[2].z, rv[3].z);
+        put(3, rv[0].w, rv[1].w, rv[2].w, rv[3].w);
     };
 
     f32x16 oacc[MB];
@@ -321,7 +318,7 @@ __global__ __launch_bounds__(NT) void flash_attn_kernel(const FlashArgs a) {
 template <int DH, int TERMS>
 void launch_dh(const Ctx& ctx, const FlashArgs& a, int B) {
     constexpr int DK = (DH + 15) / 16 * 16, DM = (DH + 31) / 32 * 32, PL = TERMS == 1 ? 1 : 2;
-    constexpr size_t kv = (size_t)2 * PL * (KT * (DK + 8) + DM * (KT + 8)) * sizeof(unsigned short);
+    constexpr size_t kv = (size_t)2 * PL * (KT * (DK + 8) + DM * (KT + 4)) * sizeof(unsigned short);
     constexpr size_t tr = (size_t)4 * 32 * (DM + 1) * sizeof(float);
     constexpr size_t lds = kv > tr ? kv : tr;
     auto kern = flash_attn_kernel<DH, TERMS>;

@@ -66,12 +66,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 struct PPArgs {
     int W, H;            // image width / height (stride 1, "same" padding: output = input geometry)
-    int NLp;             // A lines per buffer: 256 + 2 W + 2 rounded up to a multiple of 8
+    int NLp;             // A lines of one channel chunk: 256 + 2 W + 2 rounded up to a multiple of 16
+    int CAPl;            // lines of the A ring (a multiple of 16, NLp + the host's margin .. 2 NLp)
     int ntiles, tiles;   // N tiles, M tiles x N tiles
     int nci, cps;        // channel chunks in all, per K slice
     int Nb;              // rows of the packed weight that exist
     float* part;         // split-K slabs or null
-    int dbg;             // TUNE instantiation only (MAA_PP_DBG): 1 no MFMAs, 2 no copies after the prologue, 4 no fragment reads, 8 no waits
+    int dbg;             // TUNE instantiation only (MAA_PP_DBG): 1 no MFMAs, 2 no copies after the prologue, 4 no fragment reads, 8 no vmcnt wait
 };
 
 // MI x NI fragments of 32x32 per wave; a group's 128 x BN block is GWM x GWN waves (GWM GWN = 4, GWM 32 MI = 128)
@@ -85,9 +86,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     static_assert(BN % 16 == 0, "weight pieces");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     // [A buffer 0][A buffer 1][weight slot 0..2][zero line 128 B][dump 1 KB]
-    const int a_bytes = q.NLp * 128;
+    const int a_bytes = q.CAPl * 128;      // the whole A ring
     char* const sA = smem;
-    char* const sB = smem + 2 * a_bytes;
+    char* const sB = smem + a_bytes;
     char* const sZ = sB + NSB * BN * 128;
     char* const sD = sZ + 128;
 
@@ -171,15 +172,15 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     const unsigned a_swz16 = (unsigned)((sl ^ (((r8 >> 1) + 4 * (wq & 1)) & 7)) << 4);
     const int a_pieces = q.NLp >> 3;
     // any piece (prologue)
-    auto issue_a_any = [&](int ci, int pa, int buf) __attribute__((always_inline)) {
+    auto issue_a_any = [&](int ci, int pa) __attribute__((always_inline)) {
         const int line = pa * 8 + r8;
         const int P = min(max(m0 - W - 1 + line, 0), Mlast);
         const char* src = a_base + ((unsigned long long)(unsigned)P * lda4 + (unsigned long long)ci * 128u) + ((sl ^ ((line >> 1) & 7)) << 4);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + buf * a_bytes + pa * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + pa * 1024), 16, 0, 0);      // (the first chunk starts at line 0)
     };
 
     // ---- prologue: A of the first chunk and the weights of chunks 0 and 1, by all eight waves
-    for (int pa = wid; pa < a_pieces; pa += 8) issue_a_any(c_begin, pa, 0);
+    for (int pa = wid; pa < a_pieces; pa += 8) issue_a_any(c_begin, pa);
 #pragma unroll
     for (int j = 0; j < NSB - 1; ++j) {
         // (an item has at least 9 chunks)
@@ -206,58 +207,68 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
 
     // loop state (all wave-uniform): the chunk being read is (ci, t) in ring slot `slot`, its tap offset in lines `shift`;
     // the chunk whose weights are issued is two ahead: byte offset boff2 in a weight row, slot slot2, live while j + 2 < NQ
+    // A ring: the chunk being read starts at line a_o, the next one at piece a_on8 (lines a_o + NLp, wrapped)
+    const int cap8 = q.CAPl >> 3;
+    int a_o = 0, a_on8 = a_pieces >= cap8 ? a_pieces - cap8 : a_pieces;
     int ci = c_begin, t = 0, kx = 0, shift = 0, slot = 0;
     int slot2 = NSB - 1, t2 = NSB - 1;
     long long boff2 = (long long)(NSB - 1) * C4 + (long long)c_begin * 128;
 
     // memory phase of chunk j = (ci, t): fragments of the chunk into registers, this wave's pieces of chunk j + 2 and of
     // the next channel chunk's A on their way
+    auto reads = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            // line of the ring: the chunk starts at a_o and wraps at CAPl (unsigned min picks the wrapped value when it exists)
+            const unsigned l0 = (unsigned)(a_o + shift) + (unsigned)a_r[i];
+            const unsigned line = min(l0, l0 - (unsigned)q.CAPl);
+            const unsigned t1 = (unsigned)lk16 ^ ((line << 3) & 0x70u);      // lk slot bit ^ swizzle((line >> 1) & 7)
+            const bool ok = (valid9[i] >> t) & 1u;
+            // a masked lane reads the zero line: its four 16-byte pieces at zaddr + (0 .. 0x70) are all inside it
+            const unsigned base = ok ? line * 128u : zaddr;
+            ah[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x00u ^ t1)));
+            ah[1][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x20u ^ t1)));
+            al[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x40u ^ t1)));
+            al[1][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x60u ^ t1)));
+        }
+        const char* const bs = sB + slot * (BN * 128);
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bh[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[0][ks]);
+                bl[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[1][ks]);
+            }
+        }
+    };
+    auto copies = [&](int j) __attribute__((always_inline)) {
+        // weights of chunk j + 2 -> the slot chunk j - 1 has left (both groups have read it: the barrier before this tick)
+        const bool live = j + (NSB - 1) < NQ;
+        static_for<0, NPB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const bool real = live && (k * 4 + wq < BPG);       // wave-uniform
+            char* dst = real ? sB + slot2 * (BN * 128) + (grp * BPG + k * 4 + wq) * 1024 : sD;
+            __builtin_amdgcn_global_load_lds((gptr_t)(gpb[k] + boff2), (lptr_t)dst, 16, 0, 0);
+        });
+        // A of the next channel chunk: piece (2 t + grp) 4 + wq during taps 0..7
+        const int pa = (t * 2 + grp) * 4 + wq;
+        const bool real = t < TAPS - 1 && ci + 1 < c_end && pa < a_pieces;
+        const int P = min(max(a_P0 + 64 * t, 0), Mlast);
+        const char* src = a_base + ((unsigned long long)(ci + 1) * 128u) + ((unsigned long long)(unsigned)P * lda4 + a_swz16);
+        int pp = a_on8 + pa;                                  // piece of the ring (the ring and a chunk hold an even number
+        if (pp >= cap8) pp -= cap8;                           // of pieces: the swizzle parity of a piece is that of pa)
+        char* dst = real ? sA + pp * 1024 : sD;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    };
+    // memory phase of chunk j = (ci, t): the fragments of the chunk into registers, then this wave's pieces of chunk j + 2 and
+    // of the next channel chunk's A on their way.  (Measured, profiles/r3_pp_ablate_v3_order_variants.txt: copies before the
+    // reads, or the fragments waited for only at the head of the matrix phase, are both 25-30 % slower; s_setprio on either
+    // phase changes nothing.)
     auto load_phase = [&](int j) __attribute__((always_inline)) {
-        const unsigned abuf = (unsigned)(((ci - c_begin) & 1) * a_bytes);
-        if (!TUNE || !(q.dbg & 4)) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int line = a_r[i] + shift;
-                const unsigned t1 = (unsigned)lk16 ^ (((unsigned)line << 3) & 0x70u);      // lk slot bit ^ swizzle((line >> 1) & 7)
-                const bool ok = (valid9[i] >> t) & 1u;
-                // a masked lane reads the zero line: its four 16-byte pieces at zaddr + (0 .. 0x70) are all inside it
-                const unsigned base = ok ? abuf + (unsigned)line * 128u : zaddr;
-                ah[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x00u ^ t1)));
-                ah[1][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x20u ^ t1)));
-                al[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x40u ^ t1)));
-                al[1][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x60u ^ t1)));
-            }
-            const char* const bs = sB + slot * (BN * 128);
-#pragma unroll
-            for (int jn = 0; jn < NI; ++jn) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    bh[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[0][ks]);
-                    bl[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[1][ks]);
-                }
-            }
-        }
-        if (!TUNE || !(q.dbg & 2)) {
-            // weights of chunk j + 2 -> the slot chunk j - 1 has left (both groups have read it: the barrier before this tick)
-            const bool live = j + (NSB - 1) < NQ;
-            static_for<0, NPB>([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                const bool real = live && (k * 4 + wq < BPG);       // wave-uniform
-                char* dst = real ? sB + slot2 * (BN * 128) + (grp * BPG + k * 4 + wq) * 1024 : sD;
-                __builtin_amdgcn_global_load_lds((gptr_t)(gpb[k] + boff2), (lptr_t)dst, 16, 0, 0);
-            });
-            // A of the next channel chunk: piece (2 t + grp) 4 + wq during taps 0..7
-            const int pa = (t * 2 + grp) * 4 + wq;
-            const bool real = t < TAPS - 1 && ci + 1 < c_end && pa < a_pieces;
-            const int P = min(max(a_P0 + 64 * t, 0), Mlast);
-            const char* src = a_base + ((unsigned long long)(ci + 1) * 128u) + ((unsigned long long)(unsigned)P * lda4 + a_swz16);
-            char* dst = real ? sA + (abuf ^ (unsigned)a_bytes) + pa * 1024 : sD;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-        }
-        if (!TUNE || !(q.dbg & 8)) {
-            wait_lgkm0();
-            wait_vmcnt<NP>();       // all but the NP pieces just issued have landed
-        }
+        if (!TUNE || !(q.dbg & 4)) reads();
+        if (!TUNE || !(q.dbg & 2)) copies(j);
+        wait_lgkm0();
+        if (!TUNE || !(q.dbg & 8)) wait_vmcnt<NP>();       // all but the NP pieces just issued have landed
     };
     auto advance = [&]() __attribute__((always_inline)) {
         ++shift;
@@ -269,6 +280,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
             t = 0;
             shift = 0;
             ++ci;
+            a_o = a_on8 * 8;
+            a_on8 += a_pieces;
+            if (a_on8 >= cap8) a_on8 -= cap8;
         }
         if (++slot == NSB) slot = 0;
         if (++slot2 == NSB) slot2 = 0;
@@ -339,6 +353,27 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     }
 }
 
+// Lines one channel chunk of A occupies (a multiple of 16: an even number of pieces, see the swizzle parity in the kernel)
+int pp_a_lines(int W) { return (BM + 2 * W + 2 + 15) / 16 * 16; }
+// Lines of the A ring beside a weight ring of NSB x bn lines, 0 when it does not fit.  Two whole chunks (plain double
+// buffering) when there is room; else the next chunk's pieces wrap into the lines the current one no longer needs: piece pa is
+// issued during tap t = pa / 8 and lands on the current chunk's lines NLp + 8 pa - CAP .. + 7, which must lie below the
+// first line tap (ky, kx) = (t / 3, t % 3) and every later tap reads, ky W + kx.
+int pp_ring_lines(int W, int bn) {
+    const int NLp = pp_a_lines(W);
+    const int room = (163840 - 1152 - NSB * bn * 128) / 128 / 16 * 16;
+    if (room >= 2 * NLp) return 2 * NLp;
+    int X = 0;
+    for (int pa = 0; pa < NLp / 8; ++pa) {
+        const int t = pa >> 3;
+        if (t >= TAPS - 1) return 0;                       // more pieces than the eight issuing taps
+        const int need = 8 * pa + 8 - ((t / 3) * W + (t % 3));
+        if (need > X) X = need;
+    }
+    const int cap = NLp + (X + 15) / 16 * 16;
+    return cap <= room ? cap : 0;
+}
+
 template <int MI, int NI, int GWM, int GWN>
 void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part) {
     constexpr int BN = GWN * NI * 32;
@@ -347,7 +382,8 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     PPArgs q;
     q.W = p.Win;
     q.H = p.Hin;
-    q.NLp = (BM + 2 * p.Win + 2 + 7) / 8 * 8;
+    q.NLp = pp_a_lines(p.Win);
+    q.CAPl = pp_ring_lines(p.Win, BN);
     q.ntiles = ntiles;
     q.tiles = mtiles * ntiles;
     q.nci = p.C1 / BK;
@@ -355,7 +391,8 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     q.Nb = Nb;
     q.part = pl.S > 1 ? part : nullptr;
     MAA_CHECK((q.nci + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
-    const size_t lds = (size_t)2 * q.NLp * 128 + (size_t)NSB * BN * 128 + 128 + 1024;
+    MAA_CHECK(q.CAPl > 0, "igemm_pp: the A ring does not fit beside the weight ring");
+    const size_t lds = (size_t)q.CAPl * 128 + (size_t)NSB * BN * 128 + 128 + 1024;
     MAA_CHECK(lds <= 163840, "igemm_pp: LDS per workgroup");
     const int items = q.tiles * pl.S;
     q.dbg = 0;
@@ -591,8 +628,7 @@ PPPlan igemm_pp_plan(const IGemm& p) {
         return pl;
     if (!(p.a_split && p.b_split && p.b_nk && p.C2 == 0 && p.C1 % BK == 0 && p.Z == 1 && p.a_act == 0 && !p.geglu)) return pl;
     if (p.Hout != p.Hin || p.Wout != p.Win || p.K != 9 * p.C1 || p.N < 64) return pl;
-    const int NLp = (BM + 2 * p.Win + 2 + 7) / 8 * 8;
-    auto fits = [&](int bn) { return (size_t)2 * NLp * 128 + (size_t)NSB * bn * 128 + 1152 <= 163840; };
+    auto fits = [&](int bn) { return pp_ring_lines(p.Win, bn) > 0; };
     const int nci = p.C1 / BK;
     int bn = 0, S = 0;
     const char* env = std::getenv("MAA_PP");
@@ -601,8 +637,9 @@ PPPlan igemm_pp_plan(const IGemm& p) {
         std::sscanf(env, "%d,%d", &bn, &S);
     }
     if (bn != 128 && bn != 160) {
-        // N a multiple of 160 but not of 128 (320): 160-wide tiles waste nothing; else 128
-        bn = (p.N % 160 == 0 && p.N % 128 != 0 && fits(160)) ? 160 : 128;
+        // 160-wide tiles where they divide N (320, 640, 960, 1280): no padded columns at N = 320, and at N = 640 four K slices
+        // of 4 x 13 tiles make one round of 208 workgroups (profiles/r3_pp_bench_v2.txt); else 128
+        bn = (p.N % 160 == 0 && fits(160)) ? 160 : 128;
     }
     if (!fits(bn)) {
         if (bn == 160 && fits(128))
@@ -614,7 +651,7 @@ PPPlan igemm_pp_plan(const IGemm& p) {
         // enough (slice, tile) items for one round of 256 workgroups at the UNet's two resolutions without the slab round
         // trip outgrowing the contraction: N tiles x S ~ 13-16 per 256-row M tile
         const int ntiles = (p.N + bn - 1) / bn;
-        S = ntiles >= 4 ? 3 : 2;
+        S = ntiles >= 4 ? 4 : 2;
     }
     if (S > nci) S = nci;
     for (; S > 1; --S) {
@@ -664,8 +701,12 @@ PPPlan igemm_pp1_plan(const IGemm& p) {
     const bool forced = bn == 128 || bn == 160;
     if (!forced) {
         bn = (!p.geglu && ncols % 160 == 0 && ncols % 128 != 0) ? 160 : 128;
+        // Measured (profiles/r3_pp_bench_v2.txt): with 256-row tiles these short contractions are bound by how evenly the
+        // tiles fill 256 CUs, not by the K loop -- the form only wins where the tiles make several nearly full rounds (the
+        // GEGLU projection at 10x78: 980 tiles = 3.8 rounds, -7 %); everywhere else the smaller-tile engines stay.
         const long long tiles = (long long)((p.M + BM - 1) / BM) * ((ncols + bn - 1) / bn);
-        if (ncols < 128 || tiles < 96) return pl;       // too few 256-row tiles: the smaller-tile engines fill the chip better
+        const long long rounds = (tiles + 255) / 256;
+        if (ncols < 128 || tiles < 768 || rounds * 256 - tiles > 64) return pl;
     }
     if (p.geglu) bn = 128;
     const int nchunks = p.K / BK;

@@ -13,10 +13,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print(" ".join("%7.1f" % (ctx.op_bench_conv(B, H, W, ci, co, 9, True, 30) * 1e3) for _, B, H, W, ci, co in SHAPES), flush=True)
     sys.exit(0)
 print("columns (us per launch):", ", ".join(s[0] for s in SHAPES))
+VARIANTS = ((None, "product instantiation"), (0, "TUNE, everything on"), (1, "no MFMAs"), (2, "no copies"), (4, "no fragment reads"),
+            (8, "no vmcnt wait"), (3, "no MFMAs, no copies"), (5, "no MFMAs, no reads"), (6, "no copies, no reads"), (7, "barriers only"),
+            (16, "reads before copies"), (32, "fragments waited before barrier"), (48, "both (the v2 order)"), (64, "setprio 1 memory phase"),
+            (128, "setprio 1 matrix phase"))
+if len(sys.argv) > 1 and sys.argv[1] == "short":
+    VARIANTS = tuple(v for v in VARIANTS if v[0] in (None, 0, 1, 2, 16, 32, 48, 64, 128))
 for pp in ("128,1", "128,3"):
-    for dbg, what in ((None, "product instantiation"), (0, "TUNE, everything on"), (1, "no MFMAs"), (2, "no copies"), (4, "no fragment reads"),
-                      (8, "no waits"), (3, "no MFMAs, no copies"), (5, "no MFMAs, no reads"), (6, "no copies, no reads"), (7, "barriers only"),
-                      (15, "barriers only, no waits")):
+    for dbg, what in VARIANTS:
         e = dict(os.environ)
         e["MAA_PP"] = pp
         if dbg is not None:
