@@ -5,6 +5,7 @@ libaudiogpt_mi355x.so.  All tensors at this boundary are fp32, contiguous, in th
 """
 import ctypes as C
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -20,6 +21,16 @@ def default_precision():
     if p not in Context.PRECISIONS:
         raise ValueError("AUDIOGPT_AMD_PRECISION must be one of %s" % sorted(Context.PRECISIONS))
     return p
+
+
+_contexts = weakref.WeakSet()
+
+
+def reload_tuning():
+    """Make every live context parse the MAA_* tuning environment again (it is read when a context is created): tests and
+    A/B scripts call this after changing os.environ."""
+    for c in list(_contexts):
+        c.reload_tuning()
 
 
 def _f32(t, device):
@@ -50,6 +61,12 @@ class Context:
         self.lock = threading.RLock()
         self.precision = "f32"
         self.set_precision(precision)
+        _contexts.add(self)
+
+    def reload_tuning(self):
+        if getattr(self, "h", None):
+            with self.lock:
+                L.check(self.lib.maa_ctx_reload_tuning(self.h))
 
     def set_precision(self, precision):
         """Arithmetic of the contractions for models created from now on (and for the op_* calls)."""

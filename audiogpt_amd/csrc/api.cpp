@@ -124,6 +124,7 @@ int maa_ctx_create(int device_id, void* hip_stream, maa_ctx** out) {
             throw maa::Error("hipMalloc: zero page");
         }
         c->c.zeros = static_cast<float*>(z);
+        c->c.tune.load();
         *out = c;
     });
 }
@@ -136,6 +137,13 @@ int maa_ctx_destroy(maa_ctx* ctx) {
         if (ctx->c.zeros) (void)hipFree(ctx->c.zeros);
         delete ctx->c.prof;
         delete ctx;
+    });
+}
+int maa_ctx_reload_tuning(maa_ctx* ctx) {
+    return guarded([&] {
+        bind(ctx);
+        ctx->c.tune.load();
+        ctx->c.ddim_graph.clear();      // a kept step graph was captured under the old knobs
     });
 }
 int maa_ctx_synchronize(maa_ctx* ctx) {
@@ -472,8 +480,7 @@ int maa_resampler_forward(maa_ctx* ctx, maa_resampler* r, const float* d_wav, in
 // MAA_OP_PRESPLIT=1 (tests): hand the activation to the contraction in the split32 form a normalisation would
 // have written, so the op entry points exercise the LDS-DMA engines too.
 static bool op_presplit(const maa::Ctx& c, int channels, bool other_prologue) {
-    const char* e = std::getenv("MAA_OP_PRESPLIT");
-    return e && *e == '1' && c.dtype != 0 && channels % 32 == 0 && !other_prologue;
+    return c.tune.op_presplit && c.dtype != 0 && channels % 32 == 0 && !other_prologue;
 }
 
 int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w, const float* h_bias, int N,

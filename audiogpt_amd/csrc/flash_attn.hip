@@ -60,8 +60,9 @@ struct Frag {      // 8 bf16 = 4 dwords, bit-castable to the MFMA operand type
 };
 __device__ __forceinline__ bf16x8 as_bf16x8(const Frag& f) { return __builtin_bit_cast(bf16x8, f); }
 
-template <int DH, int TERMS>
-__global__ __launch_bounds__(NT) void flash_attn_kernel(const FlashArgs a) {
+// OCC: workgroups per CU the register allocation must allow (1 = whatever the kernel needs)
+template <int DH, int TERMS, int OCC>
+__global__ __launch_bounds__(NT, OCC) void flash_attn_kernel(const FlashArgs a) {
     constexpr int DK = (DH + 15) / 16 * 16;      // head dim padded to the MFMA k-step
     constexpr int DM = (DH + 31) / 32 * 32;      // rows of O^T
     constexpr int KS = DK / 16, MB = DM / 32;
@@ -112,59 +113,82 @@ __global__ __launch_bounds__(NT) void flash_attn_kernel(const FlashArgs a) {
         }
     }
 
-    // ---- K / V tile staging: thread (kb, c4) = (tid / C4, tid % C4) owns the 4 keys x 4 d block kb, c4 of both operands.
-    // K goes to LDS row by row; V is transposed in the registers it was loaded into -- component i of the four keys packs into
-    // two words -- so V^T[d][4 keys] is ONE 8-byte store per d (the 2-byte scattered stores this replaces were 5-way bank
-    // conflicts: 54 % of the kernel's LDS cycles, profiles/r2_pmc_sq_counters_dma2_first_policy.txt)
-    static_assert((KT / 4) * C4 <= NT, "one 4x4 block per thread");
-    const bool stager = tid < (KT / 4) * C4;
-    const int s_kb = tid / C4, s_c4 = tid - s_kb * C4;
-    float4 rk[4], rv[4];
+    // ---- K / V tile staging, spread over all 256 threads.
+    // K: element idx = tid + 256 j -> (key, 4 d), one row-contiguous 8-byte store per plane.
+    // V: block idx = (255 - tid) + 256 j -> (4 keys kb, 2 d c2): the two d of the four keys are transposed in the registers
+    // they were loaded into -- V^T[d][4 keys] is ONE 8-byte store per d and plane (the 2-byte scattered stores this replaces
+    // were 5-way bank conflicts: 54 % of the kernel's LDS cycles, profiles/r2_pmc_sq_counters_dma2_first_policy.txt).  The V
+    // blocks are dealt from the last thread down and the second pass of K from the first thread up, so no thread gets both
+    // extras (d = 40: threads 0-63 two K elements, 96-255 one K element + one V block).
+    constexpr int C2 = DH / 2;
+    constexpr int NK = KT * C4, NV = (KT / 4) * C2;
+    constexpr int NLK = (NK + NT - 1) / NT, NLV = (NV + NT - 1) / NT;
+    float4 rk[NLK];
+    float2 rv[NLV][4];
+    const float2* zero2 = reinterpret_cast<const float2*>(a.zeros);
     auto load_tile = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kg = kt * KT + s_kb * 4 + j;
-            const bool ok = stager && kg < a.Nk;
-            const long long row = ok ? kg : 0;
-            rk[j] = *(ok ? reinterpret_cast<const float4*>(kp + row * a.ldk + s_c4 * 4) : zero4);
-            rv[j] = *(ok ? reinterpret_cast<const float4*>(vp + row * a.ldv + s_c4 * 4) : zero4);
+        for (int j = 0; j < NLK; ++j) {
+            const int idx = tid + NT * j;
+            const int key = idx / C4, c4 = idx - key * C4;
+            const int kg = kt * KT + key;
+            const bool ok = idx < NK && kg < a.Nk;
+            rk[j] = *(ok ? reinterpret_cast<const float4*>(kp + (long long)kg * a.ldk + c4 * 4) : zero4);
+        }
+#pragma unroll
+        for (int j = 0; j < NLV; ++j) {
+            const int idx = (NT - 1 - tid) + NT * j;
+            const int kb = idx / C2, c2 = idx - kb * C2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int kg = kt * KT + kb * 4 + k;
+                const bool ok = idx < NV && kg < a.Nk;
+                rv[j][k] = *(ok ? reinterpret_cast<const float2*>(vp + (long long)kg * a.ldv + c2 * 2) : zero2);
+            }
         }
     };
     auto store_tile = [&](int buf) {
-        if (!stager) return;
         unsigned short* base = smem + buf * BUF;
         unsigned short* vt = base + PL * K_PLANE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int key = s_kb * 4 + j;
-            uint2 hi, lo;
-            if constexpr (TERMS == 1) {
-                hi.x = pk_bf16(rk[j].x, rk[j].y);
-                hi.y = pk_bf16(rk[j].z, rk[j].w);
-            } else {
-                split2(rk[j].x, rk[j].y, hi.x, lo.x);
-                split2(rk[j].z, rk[j].w, hi.y, lo.y);
-                *reinterpret_cast<uint2*>(base + K_PLANE + key * LDKK + s_c4 * 4) = lo;
+        for (int j = 0; j < NLK; ++j) {
+            const int idx = tid + NT * j;
+            if (idx < NK) {
+                const int key = idx / C4, c4 = idx - key * C4;
+                uint2 hi, lo;
+                if constexpr (TERMS == 1) {
+                    hi.x = pk_bf16(rk[j].x, rk[j].y);
+                    hi.y = pk_bf16(rk[j].z, rk[j].w);
+                } else {
+                    split2(rk[j].x, rk[j].y, hi.x, lo.x);
+                    split2(rk[j].z, rk[j].w, hi.y, lo.y);
+                    *reinterpret_cast<uint2*>(base + K_PLANE + key * LDKK + c4 * 4) = lo;
+                }
+                *reinterpret_cast<uint2*>(base + key * LDKK + c4 * 4) = hi;
             }
-            *reinterpret_cast<uint2*>(base + key * LDKK + s_c4 * 4) = hi;
         }
-        // V^T[d = 4 c4 + i][keys 4 kb .. 4 kb + 3]
-        auto put = [&](int i, float v0, float v1, float v2, float v3) {
-            uint2 hi, lo;
-            if constexpr (TERMS == 1) {
-                hi.x = pk_bf16(v0, v1);
-                hi.y = pk_bf16(v2, v3);
-            } else {
-                split2(v0, v1, hi.x, lo.x);
-                split2(v2, v3, hi.y, lo.y);
-                *reinterpret_cast<uint2*>(vt + V_PLANE + (s_c4 * 4 + i) * LDV + s_kb * 4) = lo;
+#pragma unroll
+        for (int j = 0; j < NLV; ++j) {
+            const int idx = (NT - 1 - tid) + NT * j;
+            if (idx < NV) {
+                const int kb = idx / C2, c2 = idx - kb * C2;
+                // V^T[d = 2 c2 + i][keys 4 kb .. 4 kb + 3]
+                auto put = [&](int d, float v0, float v1, float v2, float v3) {
+                    uint2 hi, lo;
+                    if constexpr (TERMS == 1) {
+                        hi.x = pk_bf16(v0, v1);
+                        hi.y = pk_bf16(v2, v3);
+                    } else {
+                        split2(v0, v1, hi.x, lo.x);
+                        split2(v2, v3, hi.y, lo.y);
+                        *reinterpret_cast<uint2*>(vt + V_PLANE + d * LDV + kb * 4) = lo;
+                    }
+                    *reinterpret_cast<uint2*>(vt + d * LDV + kb * 4) = hi;
+                };
+                put(2 * c2, rv[j][0].x, rv[j][1].x, rv[j][2].x, rv[j][3].x);
+                put(2 * c2 + 1, rv[j][0].y, rv[j][1].y, rv[j][2].y, rv[j][3].y);
             }
-            *reinterpret_cast<uint2*>(vt + (s_c4 * 4 + i) * LDV + s_kb * 4) = hi;
-        };
-        put(0, rv[0].x, rv[1].x, rv[2].x, rv[3].x);
-        put(1, rv[0].y, rv[1].y, rv[2].y, rv[3].y);
-        put(2, rv[0].z, rv[1].z, rv[2].z, rv[3].z);
-        put(3, rv[0].w, rv[1].w, rv[2].w, rv[3].w);
+        }
     };
 
     f32x16 oacc[MB];
@@ -315,13 +339,13 @@ __global__ __launch_bounds__(NT) void flash_attn_kernel(const FlashArgs a) {
     }
 }
 
-template <int DH, int TERMS>
+template <int DH, int TERMS, int OCC = 1>
 void launch_dh(const Ctx& ctx, const FlashArgs& a, int B) {
     constexpr int DK = (DH + 15) / 16 * 16, DM = (DH + 31) / 32 * 32, PL = TERMS == 1 ? 1 : 2;
     constexpr size_t kv = (size_t)2 * PL * (KT * (DK + 8) + DM * (KT + 4)) * sizeof(unsigned short);
     constexpr size_t tr = (size_t)4 * 32 * (DM + 1) * sizeof(float);
     constexpr size_t lds = kv > tr ? kv : tr;
-    auto kern = flash_attn_kernel<DH, TERMS>;
+    auto kern = flash_attn_kernel<DH, TERMS, OCC>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     dim3 grid((unsigned)((a.Nq + 127) / 128), (unsigned)(B * a.heads));
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, a);
@@ -370,6 +394,12 @@ bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, co
     const double bytes = 4.0 * B * heads * ((double)2 * Nq * dh + 2.0 * Nk * dh);
     ProfScope prof(ctx, "flash_attention", flops, bytes);
     const int terms = ctx.dtype == 1 ? 3 : 1;
+    static const bool occ4 = std::getenv("MAA_FLASH_OCC4") != nullptr;      // A/B: d = 40 capped at 128 VGPRs (4 workgroups per CU)
+    if (occ4 && dh == 40 && terms == 3) {
+        launch_dh<40, 3, 4>(ctx, a, B);
+        MAA_HIP(hipGetLastError());
+        return true;
+    }
 #define MAA_FLASH(DHV)                                 \
     if (terms == 3)                                    \
         launch_dh<DHV, 3>(ctx, a, B);                  \

@@ -309,12 +309,10 @@ __global__ __launch_bounds__(NT) void igemm_bf16_kernel(const IGemm p, int ntile
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             // chunk c + u sits in LDS stage u & 1; set u is free again
-            if (!(p.dbg & 2)) {
-                load_a(ra[u]);
-                load_b(rb[u], (c + u + PF) * BK);
-            }
-            if (c + u < nchunks && !(p.dbg & 1)) compute(u & 1);
-            if (!(p.dbg & 4)) store_tiles(ra[(u + 1) % PF], rb[(u + 1) % PF], (u + 1) & 1);
+            load_a(ra[u]);
+            load_b(rb[u], (c + u + PF) * BK);
+            if (c + u < nchunks) compute(u & 1);
+            store_tiles(ra[(u + 1) % PF], rb[(u + 1) % PF], (u + 1) & 1);
             __syncthreads();
         }
     }
@@ -406,7 +404,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     }
     static const bool no_dma = std::getenv("MAA_NO_DMA") != nullptr;      // tests: same arithmetic, register staging
     const bool dma = terms == 3 && p.a_split && p.b_split && cfg != 3 && !no_dma;
-    const PPPlan planp = dma ? igemm_pp_plan(p) : PPPlan();
+    const PPPlan planp = dma ? igemm_pp_plan(ctx, p) : PPPlan();
     if (planp.bn) {
         // halo-staged ping-pong engine for the 3x3 convolutions (igemm_pp.hip); slabs borrowed like the second engine's
         const size_t mk = ctx.ws.mark();
@@ -426,7 +424,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         ctx.ws.release(mk);
         return true;
     }
-    const PPPlan planq = dma && !planp.bn ? igemm_pp1_plan(p) : PPPlan();
+    const PPPlan planq = dma && !planp.bn ? igemm_pp1_plan(ctx, p) : PPPlan();
     if (planq.bn) {
         const size_t mk = ctx.ws.mark();
         const size_t nf = igemm_pp1_workspace_floats(p, planq);
@@ -445,7 +443,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         ctx.ws.release(mk);
         return true;
     }
-    const Dma2Plan plan2 = dma ? igemm_dma2_plan(p) : Dma2Plan();
+    const Dma2Plan plan2 = dma ? igemm_dma2_plan(ctx, p) : Dma2Plan();
     if (plan2.cfg >= 0) {
         // wide tiles + split-K; the slabs are borrowed from the arena for the duration of the two launches (stream order
         // protects them from later borrowers)
@@ -462,10 +460,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
                 name2 = shape2;
             }
             ProfScope prof2(ctx, name2, flops2, bytes2);
-            const char* dbg2 = std::getenv("MAA_DBG");          // timing ablations; read per launch like MAA_DMA2
-            IGemm q = p;
-            q.dbg = dbg2 ? std::atoi(dbg2) : 0;
-            launch_igemm_dma2(ctx, q, Nb, plan2, part);
+            launch_igemm_dma2(ctx, p, Nb, plan2, part);
             MAA_HIP(hipGetLastError());
         }
         ctx.ws.release(mk);
@@ -485,10 +480,8 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         pname = shape_name;
     }
     ProfScope prof(ctx, pname, flops, bytes);
-    static const int dbg = std::getenv("MAA_DBG") ? std::atoi(std::getenv("MAA_DBG")) : 0;   // ablation runs only
     static const int m_fastest = std::getenv("MAA_TILE_ORDER") ? std::atoi(std::getenv("MAA_TILE_ORDER")) : 0;
     IGemm q = p;
-    q.dbg = dbg;
     q.m_fastest = m_fastest && p.Z == 1;
     if (dma)
         launch_igemm_dma(ctx, q, cfg, Nb);

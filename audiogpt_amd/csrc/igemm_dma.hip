@@ -220,8 +220,8 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const IGemm p, int ntiles
     for (int c = 0; c < nchunks; ++c) {
         wait_vmcnt<(NS - 2) * IPW>();
         __builtin_amdgcn_s_barrier();
-        if (!(p.dbg & 2)) issue(st_fill);
-        if (!(p.dbg & 1)) compute(st);
+        issue(st_fill);
+        compute(st);
         st = st + 1 == NS ? 0 : st + 1;
         st_fill = st_fill + 1 == NS ? 0 : st_fill + 1;
     }

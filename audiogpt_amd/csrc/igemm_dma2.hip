@@ -22,7 +22,10 @@
 // of the operands).  New here: every copy keeps a running per-lane source pointer (one 64-bit add per copy and chunk;
 // masked rows point at the zero page with a step of 0; pointers are rebuilt only when the tap changes), the wave index
 // is scalar so LDS destinations are SALU, and the A / B role of a copy is a compile-time property of its index.
-// PIPE = true additionally software-pipelines the fragment reads inside a wave (barrier in mid-chunk).
+// The main loop software-pipelines the fragment reads inside a wave (barrier in mid-chunk).  Since round 3 the UNet's 3x3
+// convolutions run on igemm_pp.hip; this engine keeps ONE instantiation (128x128 tiles, four LDS stages) for what that one
+// does not take: ff.net.2 at 5x39, strided / wide-image convolutions (the VAE's).  The other tiles it was swept over in
+// round 2 (256x128, 128x320, 64x64, 128x64; two to five stages; unpipelined loop) are in profiles/r2_dma2_sweep*.txt.
 // Workgroups are persistent: the grid is capped at what the chip holds at once and a workgroup runs its (slice, tile)
 // items as one continuous stream of K chunks, so an item's cold start and store tail overlap its neighbours' MFMA work.
 // (Tried and dropped, profiles/r2_dma2_sweep2*.txt: touching the lines of the chunk six ahead with 4-byte LDS-DMAs as an
@@ -60,7 +63,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE>
+template <int BM, int BN, int WGM, int WGN, int NS>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm p, int ntiles, int tiles, int Nb,
                                                                      int cps, int items, float* __restrict__ part) {
     constexpr int NW = WGM * WGN, NTH = 64 * NW;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
     constexpr int IPW = AI + BI;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "copy assignment");
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % 32 == 0, "tile");
-    static_assert(NS >= (PIPE ? 3 : 2) && (NS - 2) * IPW <= 63, "stages / vmcnt field");
+    static_assert(NS >= 3 && (NS - 2) * IPW <= 63, "stages / vmcnt field");
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [NS][ROWS][128]
 
     const int tid = threadIdx.x;
@@ -295,29 +298,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue(s);
 
-    if constexpr (!PIPE) {
-        // Chunk c of the stream lives in stage c % NS.  Per chunk: wait until this wave's copies of chunk c have landed
-        // (the NS-2 younger chunks stay in flight), barrier (everybody's copies of chunk c are in LDS and everybody is
-        // done reading chunk c-1), refill the stage chunk c-1 used with chunk c+NS-1, then read + multiply chunk c.
-        int st = 0, st_fill = NS - 1;
-        for (;;) {
-            wait_vmcnt<(NS - 2) * IPW>();
-            __builtin_amdgcn_s_barrier();
-            if (!(p.dbg & 2)) issue(st_fill);
-            if (!(p.dbg & 1)) {
-                const char* base = smem + st * STAGE;
-                Frags f0, f1;
-                read_frags(base, 0, f0);
-                read_frags(base, 1, f1);
-                mma(f0);
-                mma(f1);
-            }
-            st = st + 1 == NS ? 0 : st + 1;
-            st_fill = st_fill + 1 == NS ? 0 : st_fill + 1;
-            if (--c_rem == 0)
-                if (!finish_item()) break;
-        }
-    } else {
+    {
         // Software-pipelined: the barrier sits in the middle of a chunk's MFMAs, so the fragment reads of the next
         // k-step, the barrier skew and the copy issue all hide under MFMAs of the same wave.
         //   P1(c): reads of (c, k-step 1) go out, then the MFMAs of (c, k-step 0) whose fragments were read in P2(c-1);
@@ -406,7 +387,7 @@ __global__ void splitk_reduce_kernel(const IGemm p, const float* __restrict__ pa
 // workgroup per work item instead (A/B).
 int cu_count(const Ctx& ctx) { return device_cu_count(ctx.device); }
 
-template <int BM, int BN, int WGM, int WGN, int NS, bool PIPE>
+template <int BM, int BN, int WGM, int WGN, int NS>
 void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
     constexpr int NW = WGM * WGN, NTH = 64 * NW;
     constexpr int MI = BM / WGM / 32, NI = BN / WGN / 32;
@@ -420,12 +401,11 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
     MAA_CHECK(!p.geglu || NI % 2 == 0, "GEGLU needs value / gate block pairs inside a wave");
     constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
     static_assert(lds <= 163840, "LDS per workgroup");
-    auto kern = igemm_dma2_kernel<BM, BN, WGM, WGN, NS, PIPE>;
+    auto kern = igemm_dma2_kernel<BM, BN, WGM, WGN, NS>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     const long long items = (long long)tiles * S;
-    const char* pe = std::getenv("MAA_DMA2_PERSIST");
     long long grid = items;
-    if (!pe || *pe != '0') {
+    if (ctx.tune.dma2_persist) {
         const int per_cu = (int)(163840 / lds) < 32 / NW ? (int)(163840 / lds) : 32 / NW;      // LDS- and wave-limited residency
         const long long cap = (long long)cu_count(ctx) * (per_cu < 1 ? 1 : per_cu);
         if (grid > cap) grid = cap;
@@ -447,52 +427,39 @@ int fit_slices(int nchunks, int S) {
     return S;
 }
 
-// Which problems take this engine, with which tile and how many K slices: a function of the layer (K, packed N) only.
-// MAA_DMA2 = "off" | "cfg,ns,pipe,S[,kmin[,kmax]]" overrides the policy for kmin <= K <= kmax (tuning and tests; read on
-// every launch).
-Dma2Plan plan_impl(const IGemm& p) {
+// Which problems take this engine and with how many K slices: a function of the layer (K, packed N) only.
+// MAA_DMA2 = "off" | "0,4,1,S[,kmin[,kmax]]" (tile, stages, pipelining -- one instantiation is kept -- and K slices) overrides
+// the policy for kmin <= K <= kmax; MAA_DMA2_N<packed N> does so for the layers of that width (tuning and tests; parsed when
+// the context is created).
+Dma2Plan plan_impl(const Ctx& ctx, const IGemm& p) {
     Dma2Plan pl;
     const int ncols = p.N * (p.geglu ? 2 : 1);
     const int nchunks = p.K / BK;
-    // MAA_DMA2_N<packed N> (e.g. MAA_DMA2_N320) overrides MAA_DMA2 for the layers of that width
-    char var[32];
-    std::snprintf(var, sizeof(var), "MAA_DMA2_N%d", ncols);
-    const char* env = std::getenv(var);
-    if (!env || !*env) env = std::getenv("MAA_DMA2");
-    if (env && *env) {
-        if (!std::strcmp(env, "off")) return pl;
-        int cfg = 0, ns = 2, pipe = 0, S = 1, kmin = 0, kmax = 1 << 30;
-        const int k = std::sscanf(env, "%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &kmax);
+    const std::string* env = nullptr;
+    auto it = ctx.tune.dma2_n.find(ncols);
+    if (it != ctx.tune.dma2_n.end() && !it->second.empty())
+        env = &it->second;
+    else if (!ctx.tune.dma2.empty())
+        env = &ctx.tune.dma2;
+    if (env) {
+        if (*env == "off") return pl;
+        int cfg = 0, ns = 4, pipe = 1, S = 1, kmin = 0, kmax = 1 << 30;
+        const int k = std::sscanf(env->c_str(), "%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &kmax);
         if (k >= 4) {
-            if (p.K < kmin || (p.geglu && (cfg == 2 || cfg == 3 || cfg == 4))) return pl;
-            if (p.K > kmax) env = nullptr;          // outside the override's K range: default policy below
-            if (env) {
-                pl.cfg = cfg;
-                pl.ns = ns;
-                pl.pipe = pipe;
+            MAA_CHECK(cfg == 0 && ns == 4 && pipe == 1, "MAA_DMA2: the engine keeps one instantiation, \"0,4,1,S\"");
+            if (p.K < kmin) return pl;
+            if (p.K <= kmax) {
+                pl.cfg = 0;
                 pl.S = fit_slices(nchunks, S);
                 return pl;
             }
         }
     }
-    // default policy, from the sweeps of profiles/r2_dma2_sweep*.txt and the in-pipeline A/B of r2_dma2_inpipe.txt:
-    //   * long-K contractions only (K >= 2048: the 3x3 convolutions and ff.net.2 at 5x39); below that the round-1 kernels
-    //     win (ten or twenty chunks do not amortise the wide tile's prologue and the slab round trip);
-    //   * N = 320 (the 10x78 level): one 128x320 tile holds all output channels -- no N padding (128x128 tiles waste 17 %
-    //     there) and the weights are read once per M tile;
-    //   * otherwise 128x128 tiles with the in-wave pipelined loop, four LDS stages;
-    //   * two K slices: twice the workgroups for the 5x39 level's 125 tiles at the price of one slab round trip
-    //     (more slices lose to the reduce traffic, fewer leave half the CUs idle).
+    // default policy (profiles/r2_dma2_sweep*.txt, r2_dma2_inpipe*.txt): long-K contractions only (K >= 2048:
+    // what the ping-pong engine does not take -- ff.net.2 at 5x39, the VAE's wide 3x3 convolutions); 128x128 tiles, four LDS
+    // stages, in-wave pipelined loop; two K slices (more lose to the reduce traffic, fewer leave half the CUs idle at 5x39).
     if (p.K < 2048 || ncols < 128 || p.geglu) return pl;
-    if (ncols == 320) {
-        pl.cfg = 2;
-        pl.ns = 2;
-        pl.pipe = 0;
-    } else {
-        pl.cfg = 0;
-        pl.ns = 4;
-        pl.pipe = 1;
-    }
+    pl.cfg = 0;
     pl.S = fit_slices(nchunks, 2);
     return pl;
 }
@@ -511,55 +478,23 @@ void launch_splitk_reduce(const Ctx& ctx, const IGemm& p, const float* part, int
                        ntiles, Nb, BM, BN, WGN, MI, NI);
 }
 
-Dma2Plan igemm_dma2_plan(const IGemm& p) { return plan_impl(p); }
+Dma2Plan igemm_dma2_plan(const Ctx& ctx, const IGemm& p) { return plan_impl(ctx, p); }
 
 size_t igemm_dma2_workspace_floats(const IGemm& p, const Dma2Plan& pl) {
     if (pl.cfg < 0 || pl.S <= 1) return 0;
     const int ncols = p.N * (p.geglu ? 2 : 1);
-    static const int bm[5] = {128, 256, 128, 64, 128}, bn[5] = {128, 128, 320, 64, 64};
-    MAA_CHECK(pl.cfg >= 0 && pl.cfg < 5, "igemm_dma2: tile configuration");
-    const int BM = bm[pl.cfg], BN = bn[pl.cfg];
-    const long long tiles = (long long)((p.M + BM - 1) / BM) * ((ncols + BN - 1) / BN);
-    return (size_t)(tiles * pl.S * BM * BN);
+    const long long tiles = (long long)((p.M + 127) / 128) * ((ncols + 127) / 128);
+    return (size_t)(tiles * pl.S * 128 * 128);
 }
 
-const char* igemm_dma2_name(const Dma2Plan& pl) {
-    static const char* names[5][2] = {{"igemm_dma2_bf16x3<128x128>", "igemm_dma2_bf16x3<128x128,splitK>"},
-                                      {"igemm_dma2_bf16x3<256x128>", "igemm_dma2_bf16x3<256x128,splitK>"},
-                                      {"igemm_dma2_bf16x3<128x320>", "igemm_dma2_bf16x3<128x320,splitK>"},
-                                      {"igemm_dma2_bf16x3<64x64>", "igemm_dma2_bf16x3<64x64,splitK>"},
-                                      {"igemm_dma2_bf16x3<128x64>", "igemm_dma2_bf16x3<128x64,splitK>"}};
-    return names[pl.cfg < 0 || pl.cfg > 4 ? 0 : pl.cfg][pl.S > 1];
-}
+const char* igemm_dma2_name(const Dma2Plan& pl) { return pl.S > 1 ? "igemm_dma2_bf16x3<128x128,splitK>" : "igemm_dma2_bf16x3<128x128>"; }
 
 // The caller has checked the split32 conditions (both operands split, single source, C % 32 == 0, K % 32 == 0, 16-byte
 // aligned rows, Z == 1, no A activation) and provides `part` = igemm_dma2_workspace_floats() floats when that is > 0.
 void launch_igemm_dma2(const Ctx& ctx, const IGemm& p, int Nb, const Dma2Plan& pl, float* part) {
-    MAA_CHECK(pl.cfg >= 0, "igemm_dma2: problem not planned for this engine");
+    MAA_CHECK(pl.cfg == 0, "igemm_dma2: problem not planned for this engine");
     MAA_CHECK(pl.S == 1 || part != nullptr, "igemm_dma2: split-K needs its slab workspace");
-    const int key = pl.cfg * 100 + pl.ns * 10 + pl.pipe;
-    switch (key) {
-        // 128x128 tiles, 4 waves of 64x64
-        case 20: launch_one<128, 128, 2, 2, 2, false>(ctx, p, Nb, pl.S, part); break;
-        case 30: launch_one<128, 128, 2, 2, 3, false>(ctx, p, Nb, pl.S, part); break;
-        case 31: launch_one<128, 128, 2, 2, 3, true>(ctx, p, Nb, pl.S, part); break;
-        case 41: launch_one<128, 128, 2, 2, 4, true>(ctx, p, Nb, pl.S, part); break;
-        case 51: launch_one<128, 128, 2, 2, 5, true>(ctx, p, Nb, pl.S, part); break;
-        // 256x128 tiles, 8 waves of 64x64
-        case 120: launch_one<256, 128, 4, 2, 2, false>(ctx, p, Nb, pl.S, part); break;
-        case 130: launch_one<256, 128, 4, 2, 3, false>(ctx, p, Nb, pl.S, part); break;
-        case 131: launch_one<256, 128, 4, 2, 3, true>(ctx, p, Nb, pl.S, part); break;
-        // 128x320 tiles (all of N = 320 in one tile), 8 waves of 32x160
-        case 220: launch_one<128, 320, 4, 2, 2, false>(ctx, p, Nb, pl.S, part); break;
-        // 64x64 tiles, 4 waves of 32x32: the short-K problems, as persistent workgroups
-        case 320: launch_one<64, 64, 2, 2, 2, false>(ctx, p, Nb, pl.S, part); break;
-        case 340: launch_one<64, 64, 2, 2, 4, false>(ctx, p, Nb, pl.S, part); break;
-        case 341: launch_one<64, 64, 2, 2, 4, true>(ctx, p, Nb, pl.S, part); break;
-        // 128x64 tiles, 4 waves of 64x32
-        case 430: launch_one<128, 64, 2, 2, 3, false>(ctx, p, Nb, pl.S, part); break;
-        case 441: launch_one<128, 64, 2, 2, 4, true>(ctx, p, Nb, pl.S, part); break;
-        default: MAA_CHECK(false, "igemm_dma2: no such (tile, stages, pipe) instantiation");
-    }
+    launch_one<128, 128, 2, 2, 4>(ctx, p, Nb, pl.S, part);      // 4 waves of 64x64, four LDS stages, in-wave pipelined loop
 }
 
 }  // namespace maa

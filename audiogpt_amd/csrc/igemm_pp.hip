@@ -396,8 +396,8 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     MAA_CHECK(lds <= 163840, "igemm_pp: LDS per workgroup");
     const int items = q.tiles * pl.S;
     q.dbg = 0;
-    if (const char* e = std::getenv("MAA_PP_DBG")) {      // timing ablations: a separate instantiation, never the product's
-        q.dbg = std::atoi(e);
+    if (ctx.tune.pp_dbg >= 0) {      // timing ablations (MAA_PP_DBG): a separate instantiation, never the product's
+        q.dbg = ctx.tune.pp_dbg;
         auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, true>;
         ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
         hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
@@ -621,8 +621,8 @@ void launch_one1(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float
 
 // Which problems take this engine: 3x3, stride 1, "same" zero padding, one split32 source, split32 weights, a whole number of
 // 32-channel chunks, and an image narrow enough for two A buffers + the weight ring to fit the CU's LDS.  The tile width and
-// the number of K slices depend on the layer only (never on M).  MAA_PP = "off" | "bn,S" overrides (tuning and tests).
-PPPlan igemm_pp_plan(const IGemm& p) {
+// the number of K slices depend on the layer only (never on M).  MAA_PP = "off" | "bn,S" overrides (tuning and tests; parsed when the context is created).
+PPPlan igemm_pp_plan(const Ctx& ctx, const IGemm& p) {
     PPPlan pl;
     if (!(p.KH == 3 && p.KW == 3 && p.sh == 1 && p.sw == 1 && p.dh == 1 && p.dw == 1 && p.ph == 1 && p.pw == 1 && p.up == 0))
         return pl;
@@ -631,10 +631,9 @@ PPPlan igemm_pp_plan(const IGemm& p) {
     auto fits = [&](int bn) { return pp_ring_lines(p.Win, bn) > 0; };
     const int nci = p.C1 / BK;
     int bn = 0, S = 0;
-    const char* env = std::getenv("MAA_PP");
-    if (env && *env) {
-        if (env[0] == 'o') return pl;
-        std::sscanf(env, "%d,%d", &bn, &S);
+    if (!ctx.tune.pp.empty()) {
+        if (ctx.tune.pp[0] == 'o') return pl;
+        std::sscanf(ctx.tune.pp.c_str(), "%d,%d", &bn, &S);
     }
     if (bn != 128 && bn != 160) {
         // 160-wide tiles where they divide N (320, 640, 960, 1280): no padded columns at N = 320, and at N = 640 four K slices
@@ -687,16 +686,15 @@ void launch_igemm_pp(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, f
 // 1x1 / Linear problems (both operands split32, one source, a whole number of 32-deep chunks).  Without a K split the engine
 // is bit-identical to the others, so taking it may depend on M: only when the 256-row tiles fill a useful part of the chip.
 // The number of K slices follows the second engine's layer-only rule (K >= 2048: two slices).  MAA_PP1 = "off" | "bn,S".
-PPPlan igemm_pp1_plan(const IGemm& p) {
+PPPlan igemm_pp1_plan(const Ctx& ctx, const IGemm& p) {
     PPPlan pl;
     if (!(p.KH == 1 && p.KW == 1 && p.a_split && p.b_split && p.b_nk && p.C2 == 0 && p.Z == 1 && p.a_act == 0 && p.up == 0)) return pl;
     if (p.K % BK != 0 || p.K != p.C1 || p.K < 64) return pl;
     const int ncols = p.N * (p.geglu ? 2 : 1);
     int bn = 0, S = 0;
-    const char* env = std::getenv("MAA_PP1");
-    if (env && *env) {
-        if (env[0] == 'o') return pl;
-        std::sscanf(env, "%d,%d", &bn, &S);
+    if (!ctx.tune.pp1.empty()) {
+        if (ctx.tune.pp1[0] == 'o') return pl;
+        std::sscanf(ctx.tune.pp1.c_str(), "%d,%d", &bn, &S);
     }
     const bool forced = bn == 128 || bn == 160;
     if (!forced) {

@@ -111,7 +111,20 @@ struct StepGraph {
     StepGraph& operator=(const StepGraph&) = delete;
 };
 
+// Tuning / test knobs that used to be read from the environment on every launch: parsed once when a context is created
+// (and again by maa_ctx_reload_tuning, which the tests call after changing the environment).
+struct Tuning {
+    std::string dma2;                       // MAA_DMA2 = "off" | "ns,pipe,S[,kmin[,kmax]]"
+    std::map<int, std::string> dma2_n;      // MAA_DMA2_N<packed N>
+    bool dma2_persist = true;               // MAA_DMA2_PERSIST=0: one workgroup per work item
+    std::string pp, pp1;                    // MAA_PP / MAA_PP1 = "off" | "bn,S"
+    int pp_dbg = -1;                        // MAA_PP_DBG: ablation mask of igemm_pp's TUNE instantiation (-1: product kernel)
+    bool op_presplit = false;               // MAA_OP_PRESPLIT=1: the maa_op_* test entry points hand activations over as split32
+    void load();
+};
+
 struct Ctx {
+    Tuning tune;
     StepGraph ddim_graph;
     DevSlab sampler_scratch;  // DDIM loop state (tables, step slots, UNet input, eps): reused by every sample() call
     Profiler* prof = nullptr;
@@ -164,7 +177,6 @@ struct IGemm {
     const float* zeros = nullptr;    // >= 16 B of zeros in device memory (filled in by launch_igemm)
     int m_fastest = 0;               // tile order inside an XCD's range: 1 = M-tiles fastest (MAA_TILE_ORDER=1: weights are
                                      // then fetched once chip-wide, but the conv's A re-reads lose their L2: +4 % step time)
-    int dbg = 0;                     // timing ablations (MAA_DBG): 1 skip MFMA phase, 2 skip tile loads, 4 skip LDS stores (DMA engine: barrier), 8 skip the DMA wait
 };
 void launch_igemm(const Ctx& ctx, const IGemm& p);
 // Tile choice shared by the fp32 and bf16 engines: 0 = 128x128, 1 = 128x64, 2 = 64x64 (3 = 256x32 is chosen by
@@ -178,10 +190,10 @@ void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb);
 // second LDS-DMA engine (igemm_dma2.hip): 128x128 / 256x128 tiles, 64x64 outputs per wave, split-K finished by a
 // fixed-order reduce kernel.  `takes` and the slab size depend on the layer (K, packed N) only, never on M.
 struct Dma2Plan {
-    int cfg = -1;       // -1: not taken.  tile / waves: 0 128x128 / 4, 1 256x128 / 8, 2 128x320 / 8, 3 64x64 / 4, 4 128x64 / 4
-    int ns = 2, pipe = 0, S = 1;      // LDS stages, in-wave pipelining, K slices
+    int cfg = -1;       // -1: not taken; 0: the 128x128 tile (4 waves of 64x64)
+    int ns = 4, pipe = 1, S = 1;      // LDS stages, in-wave pipelining, K slices
 };
-Dma2Plan igemm_dma2_plan(const IGemm& p);
+Dma2Plan igemm_dma2_plan(const Ctx& ctx, const IGemm& p);
 size_t igemm_dma2_workspace_floats(const IGemm& p, const Dma2Plan& pl);      // 0: no split-K for this problem
 const char* igemm_dma2_name(const Dma2Plan& pl);
 void launch_igemm_dma2(const Ctx& ctx, const IGemm& p, int Nb, const Dma2Plan& pl, float* part);
@@ -195,12 +207,12 @@ void launch_splitk_reduce(const Ctx& ctx, const IGemm& p, const float* part, int
 struct PPPlan {
     int bn = 0, S = 1;
 };
-PPPlan igemm_pp_plan(const IGemm& p);
+PPPlan igemm_pp_plan(const Ctx& ctx, const IGemm& p);
 size_t igemm_pp_workspace_floats(const IGemm& p, const PPPlan& pl);
 const char* igemm_pp_name(const PPPlan& pl);
 void launch_igemm_pp(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part);
 // ... and its 1x1 / Linear form (no halo; A and the weights share one ring)
-PPPlan igemm_pp1_plan(const IGemm& p);
+PPPlan igemm_pp1_plan(const Ctx& ctx, const IGemm& p);
 size_t igemm_pp1_workspace_floats(const IGemm& p, const PPPlan& pl);
 const char* igemm_pp1_name(const PPPlan& pl);
 void launch_igemm_pp1(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part);

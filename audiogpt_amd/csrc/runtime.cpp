@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 
+extern char** environ;
+
 namespace maa {
 
 static thread_local std::string g_last_error;
@@ -148,6 +150,27 @@ const HostTensor& get(const StateDict& sd, const std::string& name) {
     return it->second;
 }
 bool has(const StateDict& sd, const std::string& name) { return sd.find(name) != sd.end(); }
+
+void Tuning::load() {
+    auto get_s = [](const char* name) {
+        const char* e = std::getenv(name);
+        return std::string(e ? e : "");
+    };
+    dma2 = get_s("MAA_DMA2");
+    pp = get_s("MAA_PP");
+    pp1 = get_s("MAA_PP1");
+    dma2_n.clear();
+    for (char** e = ::environ; e && *e; ++e) {
+        int n = 0, used = 0;
+        if (std::sscanf(*e, "MAA_DMA2_N%d=%n", &n, &used) == 1 && used > 0) dma2_n[n] = *e + used;
+    }
+    const std::string pe = get_s("MAA_DMA2_PERSIST");
+    dma2_persist = pe.empty() || pe[0] != '0';
+    const std::string pd = get_s("MAA_PP_DBG");
+    pp_dbg = pd.empty() ? -1 : std::atoi(pd.c_str());
+    const std::string ps = get_s("MAA_OP_PRESPLIT");
+    op_presplit = !ps.empty() && ps[0] == '1';
+}
 
 void StepGraph::clear() {
     if (exec) (void)hipGraphExecDestroy(exec);

@@ -1,6 +1,7 @@
 """The wide-tile / split-K LDS-DMA engine (csrc/igemm_dma2.hip) at the operator level.
 
-Every (tile, stages, in-wave pipelining, K slices) instantiation is forced onto every eligible problem (MAA_DMA2) with
+The engine keeps one instantiation since round 3 (128x128 tiles, four stages, pipelined loop; the 3x3 convolutions moved to
+igemm_pp.hip, tests/test_gpu_pp.py); it is forced with 1 / 2 / 3 / 5 K slices onto every eligible problem (MAA_DMA2) with
 the activation handed over pre-split (MAA_OP_PRESPLIT=1, the form the normalisations write inside the models) and
 compared with torch.nn.functional in fp32 on the CPU at the bf16x3 operator tolerance (rel-max 2e-4).  Plus the
 engine's two contracts: S = 1 is bit-identical to the other bf16x3 engines, and results do not depend on the batch.
@@ -17,10 +18,8 @@ from tests.util import check
 pytestmark = pytest.mark.gpu
 
 TOL = 2e-4
-# tile cfg (0: 128x128 / 4 waves, 1: 256x128 / 8, 2: 128x320 / 8, 3: 64x64 / 4, 4: 128x64 / 4), LDS stages, in-wave
-# pipelining, K slices [, minimum K, maximum K]
-VARIANTS = ["0,2,0,1", "0,2,0,4", "0,3,0,3", "0,3,1,2", "0,4,1,5", "0,5,1,2", "1,2,0,2", "1,3,0,1", "1,3,1,3",
-            "2,2,0,1", "2,2,0,3", "3,2,0,1", "3,4,0,2", "3,4,1,1", "4,3,0,1", "4,4,1,2"]
+# tile (0: 128x128 / 4 waves), LDS stages, in-wave pipelining, K slices [, minimum K, maximum K]
+VARIANTS = ["0,4,1,1", "0,4,1,2", "0,4,1,3", "0,4,1,5"]
 
 
 @pytest.fixture(scope="module")
@@ -32,14 +31,17 @@ def ctx():
 
 
 class forced:
-    """Environment for one call: MAA_DMA2 is read by the library on every launch."""
+    """Environment for one call: the library parses the MAA_* knobs when a context is created: reload_tuning() re-reads them."""
 
     def __init__(self, dma2, presplit=True):
-        self.env = {"MAA_DMA2": dma2, "MAA_OP_PRESPLIT": "1" if presplit else "0"}
+        # (the ping-pong engines would take the 3x3 convolutions / some linears first: off)
+        self.env = {"MAA_DMA2": dma2, "MAA_OP_PRESPLIT": "1" if presplit else "0", "MAA_PP": "off", "MAA_PP1": "off"}
 
     def __enter__(self):
+        from audiogpt_amd.backend import reload_tuning
         self.saved = {k: os.environ.get(k) for k in self.env}
         os.environ.update(self.env)
+        reload_tuning()
 
     def __exit__(self, *a):
         for k, v in self.saved.items():
@@ -47,6 +49,8 @@ class forced:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        from audiogpt_amd.backend import reload_tuning
+        reload_tuning()
 
 
 def g(seed):
@@ -103,14 +107,13 @@ def test_identity_asymmetric(ctx):
     K = N = 256
     a = torch.eye(K)
     w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 17.0 + torch.arange(N)[:, None] * 0.5
-    for variant in ("0,2,0,1", "0,2,0,4", "1,3,1,2", "2,2,0,2", "0,4,1,2", "3,4,1,1", "4,3,0,2"):
+    for variant in VARIANTS:
         with forced(variant):
             y = ctx.op_linear(a, w)
         check(f"dma2[{variant}]_identity", y, w.t().contiguous(), TOL)
 
 
-@pytest.mark.parametrize("variant", ["0,2,0,1", "0,3,0,1", "0,3,1,1", "0,4,1,1", "0,5,1,1", "1,2,0,1", "1,3,1,1", "2,2,0,1",
-                                     "3,2,0,1", "3,4,0,1", "3,4,1,1", "4,3,0,1", "4,4,1,1"])
+@pytest.mark.parametrize("variant", ["0,4,1,1"])
 def test_one_slice_is_bit_identical_to_the_other_engines(ctx, variant):
     """Same products in the same order per accumulator: without a K split this engine, the 64x64 LDS-DMA engine and the
     register-staged engine agree bit for bit."""
@@ -127,7 +130,7 @@ def test_one_slice_is_bit_identical_to_the_other_engines(ctx, variant):
     assert torch.equal(y, y_reg)
 
 
-@pytest.mark.parametrize("variant", ["0,2,0,4", "1,3,1,3", "2,2,0,2", "0,4,1,2", "3,4,0,3", None])
+@pytest.mark.parametrize("variant", ["0,4,1,2", "0,4,1,3", None])
 def test_split_k_is_deterministic_and_batch_invariant(ctx, variant):
     """Slices are added in slice order by a separate kernel and their number depends on the layer only: repeated runs
     are bit-identical, and a sample's rows do not change with the batch they are computed in (None = default policy)."""
@@ -144,7 +147,7 @@ def test_split_k_is_deterministic_and_batch_invariant(ctx, variant):
     check(f"dma2[{variant}]_conv_640_b6", y6, F.conv2d(x, w, b, padding=1), TOL)
 
 
-@pytest.mark.parametrize("variant", ["3,4,0,1", "3,4,1,1", "3,2,0,2", "0,4,1,2", "4,3,0,1", "2,2,0,2"])
+@pytest.mark.parametrize("variant", ["0,4,1,1", "0,4,1,2"])
 def test_persistent_workgroups_match_one_workgroup_per_item(ctx, variant):
     """A grid smaller than the number of (slice, tile) items: every workgroup runs several items as one stream of K
     chunks (the next item's copies are issued before this item's epilogue).  Batch 16 of the benchmark's 10x78 level has
@@ -155,10 +158,12 @@ def test_persistent_workgroups_match_one_workgroup_per_item(ctx, variant):
     with forced(variant):
         y = ctx.op_conv(x, w, b, pad=1).cpu()
         os.environ["MAA_DMA2_PERSIST"] = "0"
+        ctx.reload_tuning()
         try:
             y1 = ctx.op_conv(x, w, b, pad=1).cpu()
         finally:
             os.environ.pop("MAA_DMA2_PERSIST", None)
+            ctx.reload_tuning()
     assert torch.equal(y, y1)
     check(f"dma2[{variant}]_persistent_conv_b16", y, F.conv2d(x, w, b, padding=1), TOL)
     a = torch.randn(12480, 320, generator=g(44))

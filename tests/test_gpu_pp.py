@@ -28,7 +28,7 @@ def ctx():
 
 
 class forced:
-    """Environment for one call: MAA_PP is read by the library when it plans a launch."""
+    """Environment for one call: the library parses the MAA_* knobs when a context is created: reload_tuning() re-reads them."""
 
     def __init__(self, pp, presplit=True, pp1=None, dma2=None):
         self.env = {"MAA_PP": pp, "MAA_OP_PRESPLIT": "1" if presplit else "0"}
@@ -38,8 +38,10 @@ class forced:
             self.env["MAA_DMA2"] = dma2
 
     def __enter__(self):
+        from audiogpt_amd.backend import reload_tuning
         self.saved = {k: os.environ.get(k) for k in self.env}
         os.environ.update(self.env)
+        reload_tuning()
 
     def __exit__(self, *a):
         for k, v in self.saved.items():
@@ -47,6 +49,8 @@ class forced:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        from audiogpt_amd.backend import reload_tuning
+        reload_tuning()
 
 
 def g(seed):

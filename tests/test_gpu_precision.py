@@ -177,11 +177,12 @@ np.save({out!r}, y)
 
 def test_dma_engine_bit_identical(tmp_path):
     """The LDS-DMA implicit-GEMM engines (igemm_dma.hip: 64x64 .. 128x128 tiles; igemm_dma2.hip: 128x128 tiles with 64x64
-    outputs per wave, here forced onto every eligible problem WITHOUT a K split) and the register-staged one
-    (MAA_NO_DMA=1) run the same arithmetic in the same order: a whole UNet forward (every conv / linear shape, strides,
-    upsampling, GEGLU) must agree bit for bit -- any mis-addressed tile row, swizzle slip or copy/read race shows up
-    here.  (With its default policy the second engine splits long K ranges; that changes the summation order and is
-    covered by the reference goldens and by tests/test_gpu_dma2.py instead.)"""
+    outputs per wave, here forced onto every eligible problem WITHOUT a K split; the 1x1 form of the ping-pong engine,
+    igemm_pp.hip, forced onto every eligible linear) and the register-staged one (MAA_NO_DMA=1) run the same arithmetic in
+    the same order: a whole UNet forward (every conv / linear shape, strides, upsampling, GEGLU) must agree bit for bit --
+    any mis-addressed tile row, swizzle slip or copy/read race shows up here.  (The ping-pong engine's 3x3 form orders the
+    k-steps differently and is switched off here; K splits change the summation order: both are covered by the reference
+    goldens and by tests/test_gpu_pp.py / test_gpu_dma2.py.)"""
     import os
     import subprocess
     import sys
@@ -190,12 +191,13 @@ def test_dma_engine_bit_identical(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     golden = os.path.join(root, "tests", "golden", "unet_t2a.npz")
     outs = []
-    for tag, env in (("dma", {"MAA_DMA2": "off"}), ("reg", {"MAA_NO_DMA": "1"}), ("dma2", {"MAA_DMA2": "0,2,0,1"}),
-                     ("dma2_pipe", {"MAA_DMA2": "0,4,1,1"})):
+    for tag, env in (("dma", {"MAA_DMA2": "off"}), ("reg", {"MAA_NO_DMA": "1"}), ("dma2_pipe", {"MAA_DMA2": "0,4,1,1"}),
+                     ("pp1", {"MAA_DMA2": "off", "MAA_PP1": "128,1"}), ("pp1_160", {"MAA_DMA2": "off", "MAA_PP1": "160,1"})):
         out = str(tmp_path / f"y_{tag}.npy")
         e = dict(os.environ)
         e.pop("MAA_NO_DMA", None)
         e.pop("MAA_DMA2", None)
+        e.update({"MAA_PP": "off", "MAA_PP1": "off"})
         e.update(env)
         r = subprocess.run([sys.executable, "-c", _DMA_SCRIPT.format(root=root, golden=golden, out=out)], env=e,
                            capture_output=True, text=True, timeout=600)
