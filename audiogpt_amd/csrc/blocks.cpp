@@ -45,11 +45,16 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
     p.res = o.res;
     p.ldr = out.C;
     p.act = o.act;
+    p.act_slope = o.act_slope;
     p.out_scale = o.out_scale;
     p.accumulate = o.accumulate;
     p.geglu = o.geglu;
+    p.c_split = o.c_split;
     p.c = out.p;
     p.ldc = out.C;
+    p.c2 = o.c2;
+    p.ldc2 = out.C;
+    p.c2_slope = o.c2_slope;
     launch_igemm(ctx, p);
 }
 

@@ -33,10 +33,14 @@ struct ConvOpt {
     const float* rowadd = nullptr;
     int ld_rowadd = 0;
     const float* res = nullptr;   // dense residual with the output's shape
-    int act = 0;
+    int act = 0;                  // IGemm::act (4 = leaky-relu with act_slope)
+    float act_slope = 0.f;
     float out_scale = 1.f;
     int accumulate = 0;
     int geglu = 0;
+    int c_split = 0;              // write the output as split32 lines
+    float* c2 = nullptr;          // second output: leaky-relu(c2_slope) of the result as split32 lines (output's shape)
+    float c2_slope = 1.f;
 };
 
 // out = conv(x1 ++ x2) with packed weight `w`; output spatial size given by (Ho, Wo)

@@ -152,6 +152,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI]
                     if (p.act == 1) v = tanhf(v);
                     else if (p.act == 2) v = fmaxf(v, 0.f);
                     else if (p.act == 3) v = 0.5f * v * (1.f + fast_erff(v * 0.70710678118654752440f));
+                    else if (p.act == 4) v = v > 0.f ? v : v * p.act_slope;
                     v *= p.out_scale;
                     if (p.accumulate && !p.c_split) v += cv[r];
                     outv[r] = v;
@@ -164,6 +165,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI]
                             store_split1(cp + (long long)m * p.ldc, n, outv[r]);
                         else
                             cp[(long long)m * p.ldc + n] = outv[r];
+                        if (p.c2) {
+                            const float w = outv[r] > 0.f ? outv[r] : outv[r] * p.c2_slope;
+                            store_split1(p.c2 + coff + (long long)m * p.ldc2, n, w);
+                        }
                     }
                 }
             }

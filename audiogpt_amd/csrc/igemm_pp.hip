@@ -45,7 +45,6 @@ namespace {
 constexpr int BK = 32;          // channels per chunk = one split32 line
 constexpr int BM = 256;         // output rows per workgroup
 constexpr int NSB = 3;          // weight ring
-constexpr int TAPS = 9;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -65,8 +64,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 struct PPArgs {
-    int W, H;            // image width / height (stride 1, "same" padding: output = input geometry)
-    int NLp;             // A lines of one channel chunk: 256 + 2 W + 2 rounded up to a multiple of 16
+    int W, H;            // image width / height (stride 1, "same" padding: output = input geometry; 1-D: H = 1, W = L)
+    int T, KW;           // taps, taps per kernel row (tap t = (ky, kx) = (t / KW, t % KW))
+    int rowstep, colstep;// lines between the kernel's rows / columns in the flat channels-last activation: dh W, dw
+    int dh, dw, ph, pw;  // dilation and padding (the edge masks)
+    int padflat;         // the tile's first line is flat position m0 - padflat (= ph W + pw)
+    int NLp;             // A lines of one channel chunk: 256 + the last tap's offset, rounded up to a multiple of 16
     int CAPl;            // lines of the A ring (a multiple of 16, NLp + the host's margin .. 2 NLp)
     int ntiles, tiles;   // N tiles, M tiles x N tiles
     int nci, cps;        // channel chunks in all, per K slice
@@ -76,12 +79,14 @@ struct PPArgs {
 };
 
 // MI x NI fragments of 32x32 per wave; a group's 128 x BN block is GWM x GWN waves (GWM GWN = 4, GWM 32 MI = 128)
-template <int MI, int NI, int GWM, int GWN, bool TUNE>
+// NPA: A pieces a wave issues per memory phase (1 for 3x3 / long 1-D kernels, 3 for the 3-tap 1-D kernels whose next chunk
+// has only two taps' worth of phases to arrive in)
+template <int MI, int NI, int GWM, int GWN, int NPA, bool TUNE>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPArgs q) {
     constexpr int BN = GWN * NI * 32;
     constexpr int BPG = BN / 16;                    // weight pieces (8 rows x 128 B) per group and chunk: half a chunk
     constexpr int NPB = (BPG + 3) / 4;              // ... per wave and memory phase
-    constexpr int NP = NPB + 1;                     // + one A piece
+    constexpr int NP = NPB + NPA;                   // + the A pieces
     static_assert(GWM * GWN == 4 && GWM * MI * 32 == 128, "group geometry");
     static_assert(BN % 16 == 0, "weight pieces");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -111,6 +116,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     const int m0 = mt * BM, n0 = nt * BN;
     const int c_begin = slice * q.cps;
     const int c_end = min(q.nci, c_begin + q.cps);
+    const int TAPS = q.T;
     const int NQ = (c_end - c_begin) * TAPS;
     const int W = q.W, H = q.H;
     const long long Mtot = p.M;
@@ -119,8 +125,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     if (tid < 8) *reinterpret_cast<f32x4*>(sZ + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- fragment addressing
-    // A: row r of the tile sits at line r + ky W + kx of the buffer for tap (ky, kx); 16-byte slot s of line l is stored at
-    // slot s ^ ((l >> 1) & 7).  valid9: bit t set when tap t of this lane's row is inside the image.
+    // A: row r of the tile sits at line r + ky rowstep + kx colstep of the chunk for tap (ky, kx); 16-byte slot s of line l is
+    // stored at slot s ^ ((l >> 1) & 7).  valid9: bit t set when tap t of this lane's row is inside the image.
     int a_r[MI];
     unsigned valid9[MI];
 #pragma unroll
@@ -130,9 +136,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         unsigned v = 0;
         if (m < Mtot) {
             const int ox = (int)(m % W), oy = (int)((m / W) % H);
-#pragma unroll
             for (int t = 0; t < TAPS; ++t) {
-                const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                const int iy = oy + (t / q.KW) * q.dh - q.ph, ix = ox + (t % q.KW) * q.dw - q.pw;
                 if (iy >= 0 && iy < H && ix >= 0 && ix < W) v |= 1u << t;
             }
         }
@@ -163,18 +168,16 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         gpb[k] = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4);
     }
     const int C4 = p.C1 * 4;                           // bytes between the taps of a weight row
-    // A: during tap t of channel chunk c this wave issues piece (2 t + grp) 4 + wq of chunk c + 1: its lane's line advances
-    // by 64 per tap, the swizzle term (4 pa + (r8 >> 1)) & 7 only depends on wq's parity
+    // A: during tap t of channel chunk c this wave issues pieces ((2 t + grp) 4 + wq) NPA + i of chunk c + 1
     const char* const a_base = reinterpret_cast<const char*>(p.a1);
     const unsigned lda4 = (unsigned)p.lda1 * 4u;      // bytes between positions (< 2^31)
     const int Mlast = p.M - 1;
-    const int a_P0 = m0 - W - 1 + 8 * (grp * 4 + wq) + r8;
-    const unsigned a_swz16 = (unsigned)((sl ^ (((r8 >> 1) + 4 * (wq & 1)) & 7)) << 4);
+    const int a_P0 = m0 - q.padflat + r8;             // flat position of this lane's line of piece 0
     const int a_pieces = q.NLp >> 3;
     // any piece (prologue)
     auto issue_a_any = [&](int ci, int pa) __attribute__((always_inline)) {
         const int line = pa * 8 + r8;
-        const int P = min(max(m0 - W - 1 + line, 0), Mlast);
+        const int P = min(max(m0 - q.padflat + line, 0), Mlast);
         const char* src = a_base + ((unsigned long long)(unsigned)P * lda4 + (unsigned long long)ci * 128u) + ((sl ^ ((line >> 1) & 7)) << 4);
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + pa * 1024), 16, 0, 0);      // (the first chunk starts at line 0)
     };
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     for (int pa = wid; pa < a_pieces; pa += 8) issue_a_any(c_begin, pa);
 #pragma unroll
     for (int j = 0; j < NSB - 1; ++j) {
-        // (an item has at least 9 chunks)
+        // (an item has at least T >= 3 chunks)
         for (int pb = wid; pb < BN / 8; pb += 8) {
             const int nl = 8 * pb + r8;
             const int n = min(n0 + nl, q.Nb - 1);
@@ -250,15 +253,20 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
             char* dst = real ? sB + slot2 * (BN * 128) + (grp * BPG + k * 4 + wq) * 1024 : sD;
             __builtin_amdgcn_global_load_lds((gptr_t)(gpb[k] + boff2), (lptr_t)dst, 16, 0, 0);
         });
-        // A of the next channel chunk: piece (2 t + grp) 4 + wq during taps 0..7
-        const int pa = (t * 2 + grp) * 4 + wq;
-        const bool real = t < TAPS - 1 && ci + 1 < c_end && pa < a_pieces;
-        const int P = min(max(a_P0 + 64 * t, 0), Mlast);
-        const char* src = a_base + ((unsigned long long)(ci + 1) * 128u) + ((unsigned long long)(unsigned)P * lda4 + a_swz16);
-        int pp = a_on8 + pa;                                  // piece of the ring (the ring and a chunk hold an even number
-        if (pp >= cap8) pp -= cap8;                           // of pieces: the swizzle parity of a piece is that of pa)
-        char* dst = real ? sA + pp * 1024 : sD;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        // A of the next channel chunk: pieces ((2 t + grp) 4 + wq) NPA + i during every tap but the last
+        static_for<0, NPA>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int pa = ((t * 2 + grp) * 4 + wq) * NPA + i;
+            const bool real = t < TAPS - 1 && ci + 1 < c_end && pa < a_pieces;
+            const int P = min(max(a_P0 + 8 * pa, 0), Mlast);
+            // (the ring and a chunk hold an even number of pieces: the swizzle parity of a ring piece is that of pa)
+            const unsigned swz16 = (unsigned)((sl ^ (((r8 >> 1) + 4 * (pa & 1)) & 7)) << 4);
+            const char* src = a_base + ((unsigned long long)(ci + 1) * 128u) + ((unsigned long long)(unsigned)P * lda4 + swz16);
+            int pp = a_on8 + pa;
+            if (pp >= cap8) pp -= cap8;
+            char* dst = real ? sA + pp * 1024 : sD;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        });
     };
     // memory phase of chunk j = (ci, t): the fragments of the chunk into registers, then this wave's pieces of chunk j + 2 and
     // of the next channel chunk's A on their way.  (Measured, profiles/r3_pp_ablate_v3_order_variants.txt: copies before the
@@ -271,10 +279,10 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         if (!TUNE || !(q.dbg & 8)) wait_vmcnt<NP>();       // all but the NP pieces just issued have landed
     };
     auto advance = [&]() __attribute__((always_inline)) {
-        ++shift;
-        if (++kx == 3) {
+        shift += q.colstep;
+        if (++kx == q.KW) {
             kx = 0;
-            shift += W - 3;
+            shift += q.rowstep - q.KW * q.colstep;
         }
         if (++t == TAPS) {
             t = 0;
@@ -353,25 +361,55 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     }
 }
 
-// Lines one channel chunk of A occupies (a multiple of 16: an even number of pieces, see the swizzle parity in the kernel)
-int pp_a_lines(int W) { return (BM + 2 * W + 2 + 15) / 16 * 16; }
+// Tap geometry of a problem this engine takes (igemm_pp_plan checks eligibility)
+struct PPGeom {
+    int T, KW, rowstep, colstep, padflat, NLp, npa;
+};
+PPGeom pp_geom(const IGemm& p) {
+    PPGeom g;
+    g.T = p.KH * p.KW;
+    g.KW = p.KW;
+    g.rowstep = p.dh * p.Win;
+    g.colstep = p.dw;
+    g.padflat = p.ph * p.Win + p.pw;
+    // lines one channel chunk of A occupies: 256 rows + the last tap's offset, a multiple of 16 (an even number of pieces:
+    // see the swizzle parity in the kernel)
+    g.NLp = (BM + (p.KH - 1) * g.rowstep + (p.KW - 1) * g.colstep + 15) / 16 * 16;
+    // pieces per wave and memory phase so that the next chunk arrives during all taps but the last: the kernel is
+    // instantiated for 1 and 3 (0: more than that, not taken)
+    const int need = (g.NLp / 8 + 8 * (g.T - 1) - 1) / (8 * (g.T - 1));
+    g.npa = need <= 1 ? 1 : need <= 3 ? 3 : 0;
+    return g;
+}
 // Lines of the A ring beside a weight ring of NSB x bn lines, 0 when it does not fit.  Two whole chunks (plain double
 // buffering) when there is room; else the next chunk's pieces wrap into the lines the current one no longer needs: piece pa is
-// issued during tap t = pa / 8 and lands on the current chunk's lines NLp + 8 pa - CAP .. + 7, which must lie below the
-// first line tap (ky, kx) = (t / 3, t % 3) and every later tap reads, ky W + kx.
-int pp_ring_lines(int W, int bn) {
-    const int NLp = pp_a_lines(W);
+// issued during tap t = pa / (8 npa) and lands on the current chunk's lines NLp + 8 pa - CAP .. + 7, which must lie below the
+// first line tap t = (ky, kx) and every later tap read, ky rowstep + kx colstep (the tap offsets ascend with t).
+int pp_ring_lines(const PPGeom& g, int bn) {
     const int room = (163840 - 1152 - NSB * bn * 128) / 128 / 16 * 16;
-    if (room >= 2 * NLp) return 2 * NLp;
+    if (room >= 2 * g.NLp) return 2 * g.NLp;
     int X = 0;
-    for (int pa = 0; pa < NLp / 8; ++pa) {
-        const int t = pa >> 3;
-        if (t >= TAPS - 1) return 0;                       // more pieces than the eight issuing taps
-        const int need = 8 * pa + 8 - ((t / 3) * W + (t % 3));
+    for (int pa = 0; pa < g.NLp / 8; ++pa) {
+        const int t = pa / (8 * g.npa);
+        if (t >= g.T - 1) return 0;
+        const int need = 8 * pa + 8 - ((t / g.KW) * g.rowstep + (t % g.KW) * g.colstep);
         if (need > X) X = need;
     }
-    const int cap = NLp + (X + 15) / 16 * 16;
+    const int cap = g.NLp + (X + 15) / 16 * 16;
     return cap <= room ? cap : 0;
+}
+
+template <int MI, int NI, int GWM, int GWN, int NPA>
+void launch_npa(const Ctx& ctx, const IGemm& p, const PPArgs& q, int items, size_t lds) {
+    if (ctx.tune.pp_dbg >= 0) {      // timing ablations (MAA_PP_DBG): a separate instantiation, never the product's
+        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, NPA, true>;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
+        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
+    } else {
+        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false>;
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
+        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
+    }
 }
 
 template <int MI, int NI, int GWM, int GWN>
@@ -379,33 +417,37 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     constexpr int BN = GWN * NI * 32;
     const int ncols = p.N;
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (ncols + BN - 1) / BN;
+    const PPGeom g = pp_geom(p);
     PPArgs q;
     q.W = p.Win;
     q.H = p.Hin;
-    q.NLp = pp_a_lines(p.Win);
-    q.CAPl = pp_ring_lines(p.Win, BN);
+    q.T = g.T;
+    q.KW = g.KW;
+    q.rowstep = g.rowstep;
+    q.colstep = g.colstep;
+    q.dh = p.dh;
+    q.dw = p.dw;
+    q.ph = p.ph;
+    q.pw = p.pw;
+    q.padflat = g.padflat;
+    q.NLp = g.NLp;
+    q.CAPl = pp_ring_lines(g, BN);
     q.ntiles = ntiles;
     q.tiles = mtiles * ntiles;
     q.nci = p.C1 / BK;
     q.cps = (q.nci + pl.S - 1) / pl.S;
     q.Nb = Nb;
     q.part = pl.S > 1 ? part : nullptr;
+    q.dbg = ctx.tune.pp_dbg >= 0 ? ctx.tune.pp_dbg : 0;
     MAA_CHECK((q.nci + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
     MAA_CHECK(q.CAPl > 0, "igemm_pp: the A ring does not fit beside the weight ring");
     const size_t lds = (size_t)q.CAPl * 128 + (size_t)NSB * BN * 128 + 128 + 1024;
     MAA_CHECK(lds <= 163840, "igemm_pp: LDS per workgroup");
     const int items = q.tiles * pl.S;
-    q.dbg = 0;
-    if (ctx.tune.pp_dbg >= 0) {      // timing ablations (MAA_PP_DBG): a separate instantiation, never the product's
-        q.dbg = ctx.tune.pp_dbg;
-        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, true>;
-        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
-        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
-    } else {
-        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, false>;
-        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
-        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
-    }
+    if (g.npa == 1)
+        launch_npa<MI, NI, GWM, GWN, 1>(ctx, p, q, items, lds);
+    else
+        launch_npa<MI, NI, GWM, GWN, 3>(ctx, p, q, items, lds);
     if (pl.S > 1) launch_splitk_reduce(ctx, p, part, pl.S, q.tiles, ntiles, Nb, BM, BN, GWN, MI, NI, 512);
 }
 
@@ -619,16 +661,21 @@ void launch_one1(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float
 }
 }  // namespace
 
-// Which problems take this engine: 3x3, stride 1, "same" zero padding, one split32 source, split32 weights, a whole number of
-// 32-channel chunks, and an image narrow enough for two A buffers + the weight ring to fit the CU's LDS.  The tile width and
-// the number of K slices depend on the layer only (never on M).  MAA_PP = "off" | "bn,S" overrides (tuning and tests; parsed when the context is created).
+// Which problems take this engine: stride-1 "same"-padded convolutions -- the UNet's 3x3 and the vocoders' dilated 1-D kernels
+// of 3 / 7 / 11 taps -- on one split32 source with split32 weights, a whole number of 32-channel chunks, and an A ring + the
+// weight ring that fit the CU's LDS.  The tile width and the number of K slices depend on the layer only (never on M).
+// MAA_PP = "off" | "bn,S" overrides (tuning and tests; parsed when the context is created).
 PPPlan igemm_pp_plan(const Ctx& ctx, const IGemm& p) {
     PPPlan pl;
-    if (!(p.KH == 3 && p.KW == 3 && p.sh == 1 && p.sw == 1 && p.dh == 1 && p.dw == 1 && p.ph == 1 && p.pw == 1 && p.up == 0))
-        return pl;
+    const int T = p.KH * p.KW;
+    if (!(T >= 3 && T <= 32 && p.sh == 1 && p.sw == 1 && p.up == 0)) return pl;
+    if (!(2 * p.ph == p.dh * (p.KH - 1) && 2 * p.pw == p.dw * (p.KW - 1))) return pl;          // "same" padding, odd kernels
+    if (!(p.KH == 1 || p.dh * p.Win >= (p.KW - 1) * p.dw)) return pl;                         // tap offsets ascend with t
     if (!(p.a_split && p.b_split && p.b_nk && p.C2 == 0 && p.C1 % BK == 0 && p.Z == 1 && p.a_act == 0 && !p.geglu)) return pl;
-    if (p.Hout != p.Hin || p.Wout != p.Win || p.K != 9 * p.C1 || p.N < 64) return pl;
-    auto fits = [&](int bn) { return pp_ring_lines(p.Win, bn) > 0; };
+    if (p.Hout != p.Hin || p.Wout != p.Win || p.K != T * p.C1 || p.N < 64) return pl;
+    const PPGeom g = pp_geom(p);
+    if (g.npa == 0) return pl;
+    auto fits = [&](int bn) { return pp_ring_lines(g, bn) > 0; };
     const int nci = p.C1 / BK;
     int bn = 0, S = 0;
     if (!ctx.tune.pp.empty()) {
@@ -637,7 +684,7 @@ PPPlan igemm_pp_plan(const Ctx& ctx, const IGemm& p) {
     }
     if (bn != 128 && bn != 160) {
         // 160-wide tiles where they divide N (320, 640, 960, 1280): no padded columns at N = 320, and at N = 640 four K slices
-        // of 4 x 13 tiles make one round of 208 workgroups (profiles/r3_pp_bench_v2.txt); else 128
+        // of 4 x 13 tiles make one round of 208 workgroups (profiles/r3_pp_bench_v4_ring.txt); else 128
         bn = (p.N % 160 == 0 && fits(160)) ? 160 : 128;
     }
     if (!fits(bn)) {
@@ -647,10 +694,14 @@ PPPlan igemm_pp_plan(const Ctx& ctx, const IGemm& p) {
             return pl;
     }
     if (S <= 0) {
-        // enough (slice, tile) items for one round of 256 workgroups at the UNet's two resolutions without the slab round
-        // trip outgrowing the contraction: N tiles x S ~ 13-16 per 256-row M tile
-        const int ntiles = (p.N + bn - 1) / bn;
-        S = ntiles >= 4 ? 4 : 2;
+        if (p.KH == 1) {
+            S = 1;      // the vocoders' layers: tens of thousands of rows, thousands of tiles
+        } else {
+            // enough (slice, tile) items for one round of ~200 workgroups at the UNet's two resolutions without the slab round
+            // trip outgrowing the contraction
+            const int ntiles = (p.N + bn - 1) / bn;
+            S = ntiles >= 4 ? 4 : 2;
+        }
     }
     if (S > nci) S = nci;
     for (; S > 1; --S) {

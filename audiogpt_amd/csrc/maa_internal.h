@@ -168,12 +168,18 @@ struct IGemm {
     const float* res = nullptr;      // residual, same indexing as c
     int ldr = 0;
     int geglu = 0;                   // value/gate column interleave (see pack.cpp), writes N/2 columns
-    int act = 0;                     // 0 none, 1 tanh, 2 relu, 3 gelu (erf)
+    int act = 0;                     // 0 none, 1 tanh, 2 relu, 3 gelu (erf), 4 leaky-relu(act_slope)
+    float act_slope = 0.f;
     float out_scale = 1.f;           // applied after bias/residual/act
     int accumulate = 0;              // c += value instead of c = value
     int c_split = 0;                 // write the output as split32 lines (bf16 engine only; no accumulate, Z == 1)
     float* c = nullptr;
     int ldc = 0;
+    // optional second output: leaky-relu(c2_slope) of the final value as split32 lines, same indexing as c with pitch ldc2 --
+    // the next convolution's pre-activated, pre-split input (the vocoders' MRF chains)
+    float* c2 = nullptr;
+    int ldc2 = 0;
+    float c2_slope = 1.f;
     const float* zeros = nullptr;    // >= 16 B of zeros in device memory (filled in by launch_igemm)
     int m_fastest = 0;               // tile order inside an XCD's range: 1 = M-tiles fastest (MAA_TILE_ORDER=1: weights are
                                      // then fetched once chip-wide, but the conv's A re-reads lose their L2: +4 % step time)
@@ -229,7 +235,7 @@ void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, con
                       float eps, float* out, int out_split = 0);
 // fp32 [rows, C] -> split32 rows of the same pitch (C % 32 == 0): tests and micro-benchmarks of the engines that take
 // pre-split activations (in the models the normalisations write this form directly)
-void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, float* out);
+void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, float* out, float slope = 1.f);
 // fused softmax(alpha q k^T) v for the bf16 precision modes; false = shape not covered, use the GEMM path
 bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
                             const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,

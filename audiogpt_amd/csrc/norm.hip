@@ -255,24 +255,31 @@ __global__ __launch_bounds__(256) void softmax_kernel(float* __restrict__ s, lon
 }
 
 // fp32 rows -> split32 rows (same pitch): what a normalisation with out_split = 1 does to its result, on its own
-__global__ __launch_bounds__(256) void split32_pack_kernel(const float* __restrict__ x, long long rows, int C,
+// (slope != 1: leaky-relu first -- the pre-activated input of the vocoders' first MRF convolution)
+__global__ __launch_bounds__(256) void split32_pack_kernel(const float* __restrict__ x, long long rows, int C, float slope,
                                                            float* __restrict__ out) {
     const long long n4 = rows * (C / 4);
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         const long long row = i / (C / 4);
         const int c = (int)(i - row * (C / 4)) * 4;
-        store4(out, row, c, C, 1, *reinterpret_cast<const float4*>(x + row * C + c));
+        float4 v = *reinterpret_cast<const float4*>(x + row * C + c);
+        v.x = v.x > 0.f ? v.x : v.x * slope;
+        v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope;
+        v.w = v.w > 0.f ? v.w : v.w * slope;
+        store4(out, row, c, C, 1, v);
     }
 }
 
 }  // namespace
 
-void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, float* out) {
+void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, float* out, float slope) {
     if (ctx.ws.dry) return;
+    ProfScope prof(ctx, "split32_pack_kernel", 0.0, 8.0 * rows * (double)C);
     MAA_CHECK(C % 32 == 0, "split32 rows are whole 32-channel lines");
     const long long n4 = rows * (C / 4);
     const unsigned grid = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
-    hipLaunchKernelGGL(split32_pack_kernel, dim3(grid), dim3(256), 0, ctx.stream, x, rows, C, out);
+    hipLaunchKernelGGL(split32_pack_kernel, dim3(grid), dim3(256), 0, ctx.stream, x, rows, C, slope, out);
     MAA_HIP(hipGetLastError());
 }
 

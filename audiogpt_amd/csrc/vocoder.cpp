@@ -202,6 +202,31 @@ struct Vocoder::Impl {
         conv_into(ctx, x, nullptr, c.w, o, out);
     }
 
+    // The same conv on a PRE-ACTIVATED, PRE-SPLIT input (split32 lines of leaky(x)): both operands go to LDS by DMA and the
+    // contraction runs on the ping-pong engine (igemm_pp.hip).  post_slope != 0: the output is leaky(result) as split32 lines
+    // (c1 of an MRF pair: only the next convolution reads it); else fp32 with the residual / scale / accumulate epilogue, and
+    // next_split != null additionally receives leaky(result) as split32 lines -- the next pair's input.
+    void conv1d_split(Ctx& ctx, const T4& xs, const ConvK& c, float post_slope, const float* res, float out_scale,
+                      int accumulate, T4& out, float* next_split, float next_slope) {
+        ConvOpt o;
+        o.KH = 1;
+        o.KW = c.k;
+        o.dil = c.dil;
+        o.pad = (c.k * c.dil - c.dil) / 2;
+        o.pad_h = 0;
+        o.res = res;
+        o.out_scale = out_scale;
+        o.accumulate = accumulate;
+        if (post_slope != 0.f) {
+            o.act = 4;
+            o.act_slope = post_slope;
+            o.c_split = 1;
+        }
+        o.c2 = next_split;
+        o.c2_slope = next_slope;
+        conv_into(ctx, xs, nullptr, c.w, o, out);
+    }
+
     // har: harmonic source [B, T*hop] of the NSF branch, or null
     void forward(Ctx& ctx, const float* mel, int B, int T, float* wav, const float* har = nullptr) {
         const bool big = cfg.kind == 1;
@@ -271,17 +296,47 @@ struct Vocoder::Impl {
             }
             // MRF: x = (rb_0(y) + rb_1(y) + rb_2(y)) / n on the SAME input (hifigan.py:158-164)
             T4 xs = alloc_t(ctx, B, 1, L, u.cout);
-            const size_t mk = ctx.ws.mark();
             const float inv_n = 1.0f / (float)cfg.n_kernels;
+            // Wide HiFi-GAN stages in the bf16x3 mode: every MRF convolution reads a pre-activated, pre-split input --
+            // leaky(x) as split32 lines, written by the producer's epilogue -- so that both operands reach LDS by DMA and
+            // the contraction runs on the ping-pong engine (C >= 128: the layer is matrix work, not HBM traffic; the
+            // narrow stages keep the halo kernel).
+            const bool presplit = !big && ctx.dtype == 1 && u.cout >= 128 && u.cout % 32 == 0;
+            T4 ys;
+            if (presplit) {
+                ys = alloc_t(ctx, B, 1, L, u.cout);
+                ys.split = true;
+                launch_split32_pack(ctx, y.p, (long long)B * L, u.cout, ys.p, 0.1f);
+            }
+            const size_t mk = ctx.ws.mark();      // (per-resblock scratch below is given back after each resblock; ys stays)
             for (int j = 0; j < cfg.n_kernels; ++j) {
                 const ResBlockW& rb = rbs[i * cfg.n_kernels + j];
                 T4 cur = y;
                 T4 t1 = alloc_t(ctx, B, 1, L, u.cout);
                 T4 bufA = alloc_t(ctx, B, 1, L, u.cout), bufB = alloc_t(ctx, B, 1, L, u.cout);
                 T4 act = big ? alloc_t(ctx, B, 1, L, u.cout) : T4();
+                T4 sA, sB, cur_s = ys;
+                if (presplit) {
+                    sA = alloc_t(ctx, B, 1, L, u.cout);
+                    sB = alloc_t(ctx, B, 1, L, u.cout);
+                    sA.split = sB.split = t1.split = true;
+                }
                 for (size_t mth = 0; mth < rb.c1.size(); ++mth) {
                     const bool last = mth + 1 == rb.c1.size();
                     // xt = c1(act(x)); xt = c2(act(xt)); x = xt + x      (hifigan.py:54-61 / bigvgan models.py:72-81)
+                    if (presplit) {
+                        conv1d_split(ctx, cur_s, rb.c1[mth], 0.1f, nullptr, 1.f, 0, t1, nullptr, 1.f);      // t1 = split(leaky(c1(.)))
+                        if (last) {
+                            conv1d_split(ctx, t1, rb.c2[mth], 0.f, cur.p, inv_n, j > 0, xs, nullptr, 1.f);
+                        } else {
+                            T4& dst = (cur.p == bufA.p) ? bufB : bufA;
+                            T4& dst_s = (cur_s.p == sA.p) ? sB : sA;
+                            conv1d_split(ctx, t1, rb.c2[mth], 0.f, cur.p, 1.f, 0, dst, dst_s.p, 0.1f);
+                            cur = dst;
+                            cur_s = dst_s;
+                        }
+                        continue;
+                    }
                     if (big) {
                         launch_snake_aa(ctx, cur.p, B, L, u.cout, rb.inv_beta[2 * mth], rb.alpha[2 * mth], act.p);
                         conv1d(ctx, act, rb.c1[mth], 0.f, nullptr, 1.f, 0, t1);

@@ -350,7 +350,40 @@ def run_mixed(dev, precision, steps, warmup, n=PROMPTS_PER_GPU, S=DDIM_STEPS, ro
     return res
 
 
-def main():
+class _StubPipe:
+    """CPU stand-in for a MakeAnAudio replica (--stub-cpu: the N > 1 control flow of this file under gloo, tests/test_shard_gloo.py):
+    a deterministic per-sample function of (x_T, c, uc) with the pipeline's output shapes in miniature."""
+    stream = None
+    ctx = None
+
+    def generate_here(self, x_T, c, uc, scale, S, use_graph=True):
+        feat = (c.mean(dim=(1, 2)) - uc.mean(dim=(1, 2)))[:, None] * scale + x_T.reshape(x_T.shape[0], -1).sum(dim=1, keepdim=True)
+        wav = torch.sin(feat * 0.01 + torch.arange(64, dtype=torch.float32)[None, :] * 0.1)
+        return wav, None, None
+
+    generate = generate_here
+
+    def audio_seconds(self, n, frames):
+        return n * frames * 256 / 16000.0
+
+    def close(self):
+        pass
+
+
+class _NullEvent:
+    """torch.cuda.Event's surface on the CPU path."""
+
+    def __init__(self, enable_timing=False):
+        pass
+
+    def record(self, stream=None):
+        pass
+
+    def elapsed_time(self, other):
+        return 0.0
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
@@ -373,15 +406,24 @@ def main():
     ap.add_argument("--inflight", type=int, default=3,
                     help="prompt batches in flight per GPU: consecutive steps (independent batches of 8 prompts) run on this many "
                          "pipeline replicas / HIP streams, as a serving loop would overlap requests; 1 = strictly one after another")
-    args = ap.parse_args()
+    ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)      # tests: this file's control flow on CPU / gloo
+    ap.add_argument("--json-out", default=None, help=argparse.SUPPRESS)              # tests: also write the line to a file
+    args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, "launch with --nproc-per-node == --gpus"
-    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    stub = args.stub_cpu
+    if stub:
+        args.no_roofline = args.no_cpu_baseline = args.no_secondary = True
+        args.workload = "t2a"
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    Event = _NullEvent if stub else torch.cuda.Event
     if args.workload == "hifigan64":
         assert world == 1, "the vocoder-only workload is a single-GPU configuration"
         print(json.dumps(run_hifigan64(dev, args.precision, args.steps, args.warmup, not args.no_cpu_baseline,
@@ -396,7 +438,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from concurrent.futures import ThreadPoolExecutor
 
@@ -411,11 +456,15 @@ def main():
     # each replica on its own (non-blocking) torch stream: with the library's default blocking streams every op on PyTorch's
     # legacy default stream -- the clamp between VAE and vocoder, the collectives' bookkeeping -- is a barrier across all
     # replicas (--legacy-streams keeps that arrangement for A/B runs)
-    pipes = [MakeAnAudio(dev, precision=args.precision, stream=None if args.legacy_streams else torch.cuda.Stream(dev))
-             for _ in range(inflight)]
+    if stub:
+        pipes = [_StubPipe() for _ in range(inflight)]
+    else:
+        pipes = [MakeAnAudio(dev, precision=args.precision, stream=None if args.legacy_streams else torch.cuda.Stream(dev))
+                 for _ in range(inflight)]
     pipe = pipes[0]
     # worker threads start with torch's thread-local device at 0: pin them to this rank's GPU (no stray context on GPU 0)
-    pool = ThreadPoolExecutor(max_workers=inflight, initializer=torch.cuda.set_device, initargs=(dev,))
+    pool = ThreadPoolExecutor(max_workers=inflight) if stub else \
+        ThreadPoolExecutor(max_workers=inflight, initializer=torch.cuda.set_device, initargs=(dev,))
     n = args.prompts_per_gpu
     S = args.ddim_steps
     use_graph = not args.no_graph
@@ -436,10 +485,10 @@ def main():
         def generate(c_, uc_, ready):
             """One prompt batch on replica p_ (worker thread): everything on the replica's own stream, after the event the
             main thread recorded behind this batch's conditioning; returns the waveforms and the event that marks them done."""
-            done = torch.cuda.Event()
+            done = Event()
             if p_.stream is None:
                 wav = p_.generate_here(x_T, c_, uc_, CFG_SCALE, S, use_graph=use_graph)[0]
-                done.record(torch.cuda.current_stream(dev))
+                done.record(None if stub else torch.cuda.current_stream(dev))
             else:
                 with torch.cuda.stream(p_.stream):
                     p_.stream.wait_event(ready)
@@ -453,21 +502,22 @@ def main():
     comm_events = {"C1_broadcast": [], "C2_gather": []}      # (start, end) event pairs around the two collectives, per step
 
     def conditioning():
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = Event(enable_timing=True), Event(enable_timing=True)
         e0.record()
         c, uc = broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape)          # C1: RCCL broadcast (no-op at N = 1)
         e1.record()
         comm_events["C1_broadcast"].append((e0, e1))
-        ready = torch.cuda.Event()
+        ready = Event()
         ready.record()
         return c, uc, ready
 
     def gather(res):
         wav, done = res
-        cur = torch.cuda.current_stream()
-        cur.wait_event(done)
-        wav.record_stream(cur)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if not stub:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(done)
+            wav.record_stream(cur)
+        e0, e1 = Event(enable_timing=True), Event(enable_timing=True)
         e0.record()
         out = gather_waveforms(wav, dist, counts=counts)                                       # C2: gather to rank 0
         e1.record()
@@ -483,7 +533,8 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     run_steps(args.warmup * inflight)      # W untimed steps on every replica (each sizes its workspace, builds its graphs)
     barrier()
@@ -545,6 +596,7 @@ def main():
                     and abs(e["launches_per_ddim_step"] - mine) <= 0.03 * mine:
                 result["roofline"]["traffic"] = e["hbm_bytes_per_launch"]
                 result["roofline"]["traffic_note"] = t["note"]
+                result["roofline"]["mfma_busy"] = e.get("mfma_busy")      # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, same PMC call
             else:
                 result["roofline"]["traffic_note"] = "profiles/pmc_traffic.json does not match this binary / launch mix: not reported"
         if args.breakdown:
@@ -556,11 +608,11 @@ def main():
     if rank == 0 and world == 1 and inflight > 1 and args.steps >= 2:
         # the same K steps strictly one batch after another on one stream (the latency-oriented number)
         k1 = min(args.steps, 3)
-        torch.cuda.synchronize()
+        barrier()
         t0 = time.perf_counter()
         for _ in range(k1):
             pipe.generate(x_T, c_all[:n], uc_row.expand(n, -1, -1).contiguous(), CFG_SCALE, S, use_graph=use_graph)
-        torch.cuda.synchronize()
+        barrier()
         one = time.perf_counter() - t0
         result["one_batch_in_flight"] = {"value": pipe.audio_seconds(n, CLIP_FRAMES) * k1 / one, "ms_per_step": 1e3 * one / k1,
                                          "steps": k1}
@@ -576,7 +628,13 @@ def main():
             except Exception as e:      # never lose the headline line to a secondary workload
                 result["secondary"][name] = {"error": str(e)[:300]}
     if rank == 0:
+        if stub:
+            result["data"] = "stub pipeline on CPU (control-flow test): not a measurement"
+            result["last_gather_shape"] = list(out.shape) if out is not None else None
         print(json.dumps(result), flush=True)
+        if args.json_out:
+            with open(args.json_out, "w") as f:
+                f.write(json.dumps(result))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -13,10 +13,10 @@ rm -rf gpurun_out/prof_$tag
 # HBM-side traffic of the kernels (separate PMC passes, kernel-trace only), short eager workload with the bench's launch mix
 STEPS=4
 rm -f gpurun_out/${tag}_${prec}_pmc_fetch_write.txt
-for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
-  n=$(echo $set | cut -d_ -f1)
+for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
+  n=$(echo $set | cut -d_ -f1-2 | tr -d ' ')
   timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmc_${tag}_$n -o pmc -- python scripts/pmc_workload.py $prec $STEPS > gpurun_out/pmc_${tag}_$n.log 2>&1
-  echo "== $set  ($STEPS DDIM steps, 8 latents + CFG, $prec)" >> gpurun_out/${tag}_${prec}_pmc_fetch_write.txt
+  echo "== $(echo $set | cut -d' ' -f1)  [$set]  ($STEPS DDIM steps, 8 latents + CFG, $prec)" >> gpurun_out/${tag}_${prec}_pmc_fetch_write.txt
   python scripts/pmc_summary.py gpurun_out/pmc_${tag}_$n/pmc_results.db 30 | grep -v "^# columns" >> gpurun_out/${tag}_${prec}_pmc_fetch_write.txt 2>&1
   rm -rf gpurun_out/pmc_${tag}_$n gpurun_out/pmc_${tag}_$n.log
 done

@@ -19,23 +19,30 @@ LABELS = {  # bench.py / maa_prof label -> (rocprof kernel prefixes, prefix whos
     "igemm_dma_bf16x3<128x64>": (["igemm_dma_kernel<128, 64"], "igemm_dma_kernel<128, 64"),
     "igemm_dma_bf16x3<128x128>": (["igemm_dma_kernel<128, 128"], "igemm_dma_kernel<128, 128"),
     "igemm_dma2_bf16x3<128x128,splitK>": (["igemm_dma2_kernel<128, 128", "splitk_reduce_kernel"], "igemm_dma2_kernel<128, 128"),
-    "igemm_dma2_bf16x3<128x320,splitK>": (["igemm_dma2_kernel<128, 320"], "igemm_dma2_kernel<128, 320"),
+    "igemm_dma2_bf16x3<128x128>": (["igemm_dma2_kernel<128, 128"], "igemm_dma2_kernel<128, 128"),
+    "igemm_pp_bf16x3<256x128,splitK>": (["igemm_pp_kernel<2, 2, 2, 2", "splitk_reduce_kernel"], "igemm_pp_kernel<2, 2, 2, 2"),
+    "igemm_pp_bf16x3<256x160,splitK>": (["igemm_pp_kernel<1, 5, 4, 1", "splitk_reduce_kernel"], "igemm_pp_kernel<1, 5, 4, 1"),
+    "igemm_pp_bf16x3<256x128>": (["igemm_pp_kernel<2, 2, 2, 2"], "igemm_pp_kernel<2, 2, 2, 2"),
+    "igemm_pp_bf16x3<256x160>": (["igemm_pp_kernel<1, 5, 4, 1"], "igemm_pp_kernel<1, 5, 4, 1"),
+    "igemm_pp1_bf16x3<256x128>": (["igemm_pp1_kernel<2, 2, 2, 2"], "igemm_pp1_kernel<2, 2, 2, 2"),
     "igemm_f32<64x64>": (["igemm_f32_kernel<64, 64"], "igemm_f32_kernel<64, 64"),
     "igemm_f32<128x64>": (["igemm_f32_kernel<128, 64"], "igemm_f32_kernel<128, 64"),
     "igemm_f32<128x128>": (["igemm_f32_kernel<128, 128"], "igemm_f32_kernel<128, 128"),
 }
-rows = {"FETCH_SIZE": {}, "WRITE_SIZE": {}}          # counter -> kernel name -> (launches, sum KB)
+rows = {"FETCH_SIZE": {}, "WRITE_SIZE": {}, "SQ_VALU_MFMA_BUSY_CYCLES": {}, "GRBM_GUI_ACTIVE": {}}   # counter -> kernel name -> (launches, sum)
 section = None
 for line in open(path):
     if line.startswith("=="):
         section = line.split()[1]
         continue
     m = re.search(r"^(.*?)\s+grid\s+\S+\s+launches\s+(\d+)", line)
-    if section in rows and m:
-        v = re.search(section + r"=([0-9.eE+-]+)", line)
-        if v:
-            n0, s0 = rows[section].get(m.group(1).strip(), (0, 0.0))
-            rows[section][m.group(1).strip()] = (n0 + int(m.group(2)), s0 + float(v.group(1)))
+    if m:
+        # (a reduce launch shared by several split-K engines is attributed to each: an upper bound on their traffic)
+        for c in ([section] if section in ("FETCH_SIZE", "WRITE_SIZE") else ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"] if section == "SQ_VALU_MFMA_BUSY_CYCLES" else []):
+            v = re.search(c + r"=([0-9.eE+-]+)", line)
+            if v:
+                n0, s0 = rows[c].get(m.group(1).strip(), (0, 0.0))
+                rows[c][m.group(1).strip()] = (n0 + int(m.group(2)), s0 + float(v.group(1)))
 kernels = {}
 for label, (prefixes, count_prefix) in LABELS.items():
     tot, n = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}, 0
@@ -49,12 +56,19 @@ for label, (prefixes, count_prefix) in LABELS.items():
         kernels[label] = {"hbm_bytes_per_launch": (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / n,
                           "fetch_kb_sum": tot["FETCH_SIZE"], "write_kb_sum": tot["WRITE_SIZE"], "launches": n,
                           "launches_per_ddim_step": n / float(steps)}
+        # matrix-pipe occupancy of the GEMM launch itself (the reduce launch has no MFMAs): SQ_VALU_MFMA_BUSY_CYCLES counts
+        # busy cycles summed over the chip's 1024 SIMDs, GRBM_GUI_ACTIVE the kernel's cycles summed over the 8 XCDs
+        busy = sum(v for name, (ln, v) in rows["SQ_VALU_MFMA_BUSY_CYCLES"].items() if name.startswith(count_prefix))
+        act = sum(v for name, (ln, v) in rows["GRBM_GUI_ACTIVE"].items() if name.startswith(count_prefix))
+        if busy and act:
+            kernels[label]["mfma_busy"] = busy / (act / 8.0 * 1024.0)
 from audiogpt_amd.build import _source_hash  # noqa: E402
 json.dump({"precision": prec, "source_hash": _source_hash(), "ddim_steps": steps, "kernels": kernels,
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate kernel-trace passes over %d eager DDIM steps of the "
                    "benchmark batch (8 latents + CFG); HBM-side bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, "
                    "MI355X_MICROARCH.md) + WRITE_SIZE, per launch of the labelled contraction (a split-K contraction includes "
-                   "its reduce launch); Infinity-Cache hits are counted by these counters; source %s" % (steps, path)},
+                   "its reduce launch); Infinity-Cache hits are counted by these counters; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) "
+                   "of the GEMM launch, from a third pass; source %s" % (steps, path)},
           open(out, "w"), indent=1)
 for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["launches"]):
     print("%-40s %8.1f MB per launch  (%d launches, %.1f per DDIM step)" % (k, v["hbm_bytes_per_launch"] / 1e6, v["launches"], v["launches_per_ddim_step"]))

@@ -180,3 +180,22 @@ def test_linear_form_is_bit_identical_to_the_other_engines(ctx):
         y2 = ctx.op_linear(a, w, b).cpu()
     with forced("off", pp1="128,2"):
         assert torch.equal(ctx.op_linear(a, w, b).cpu(), y2)
+
+
+# ---------------------------------------------------------------------------------------------- dilated 1-D kernels (vocoders)
+@pytest.mark.parametrize("k,dil", [(3, 1), (3, 5), (7, 1), (7, 3), (11, 1), (11, 5)])
+@pytest.mark.parametrize("B,C,Cout,L", [(2, 128, 128, 1000), (3, 256, 256, 300), (1, 512, 512, 77)])
+def test_conv1d_dilated(ctx, k, dil, B, C, Cout, L):
+    """The MRF convolutions of the wide HiFi-GAN stages: "same" padding, 3 / 7 / 11 taps, dilation 1 / 3 / 5; L = 300 and
+    77 put several samples into one 256-row tile (every edge mask in play); the 3-tap kernels take the instantiation that
+    issues three A pieces per memory phase."""
+    x = torch.randn(B, C, 1, L, generator=g(51))
+    w = torch.randn(Cout, C, 1, k, generator=g(52)) / math.sqrt(k * C)
+    b = torch.randn(Cout, generator=g(53))
+    pad = dil * (k - 1) // 2
+    ctx.prof_begin(detail=True)
+    with forced(""):
+        y = ctx.op_conv(x, w, b, pad=pad, dil=dil)
+    rows = ctx.prof_end()
+    assert any(r.startswith("pp") for r in rows), rows.keys()
+    check(f"pp_conv1d_k{k}_d{dil}_{C}_{Cout}_L{L}_b{B}", y, F.conv2d(x, w, b, padding=(0, pad), dilation=(1, dil)), TOL)

@@ -154,3 +154,31 @@ def test_batches_in_flight_keep_the_collective_order(tmp_path, steps, inflight):
         c_all, uc_row = torch.randn(n_total, 7, 16, generator=g), torch.randn(1, 7, 16, generator=g)
         c, uc = shard.broadcast_conditioning(c_all, uc_row, n_total, torch.device("cpu"), None)
         assert np.array_equal(got[i], _fake_generate(x_T, c, uc).numpy()), i
+
+
+def _bench_worker(rank, world, port, out_path, inflight):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank),
+                       "WORLD_SIZE": str(world)})
+    import bench
+    bench.main(["--gpus", str(world), "--steps", "4", "--warmup", "1", "--inflight", str(inflight), "--stub-cpu",
+                "--json-out", out_path])
+
+
+@pytest.mark.parametrize("inflight", [1, 3])
+def test_bench_main_multi_rank_control_flow(tmp_path, inflight):
+    """bench.py's own N > 1 path end to end under gloo with a stub pipeline (two ranks): process-group set-up, C0 start codes,
+    C1 broadcast and C2 gather issued in step order around worker threads that keep `inflight` batches going, the barrier /
+    max-over-ranks timing, and ONE JSON line on rank 0 that follows the contract (whole-job value over both ranks)."""
+    import json
+    world, out = 2, str(tmp_path / "line.json")
+    mp.spawn(_bench_worker, args=(world, _free_port(), out, inflight), nprocs=world, join=True)
+    d = json.load(open(out))
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"]
+    assert d["config"]["batches_in_flight"] == inflight and d["config"]["prompts_per_gpu"] == 8
+    assert ("in flight" in d["metric"]) == (inflight > 1)
+    # value = audio-seconds of ALL ranks' prompts per step / seconds per step
+    assert abs(d["value"] - d["config"]["audio_seconds_per_step"] / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
+    assert abs(d["config"]["audio_seconds_per_step"] - 2 * 8 * 624 * 256 / 16000.0) < 1e-9
+    assert d["last_gather_shape"] == [16, 64]                     # rank 0 ends up with both ranks' waveforms
+    assert set(d["comm_ms_per_step"]) == {"C1_broadcast", "C2_gather"}
+    assert "roofline" not in d and "cpu_baseline" not in d         # N > 1 lines carry neither (and the stub measures nothing)
