@@ -391,6 +391,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         MAA_CHECK(!p.a_split && !p.b_split, "split operand given to a problem the bf16 engine cannot take");
         return false;
     }
+    MAA_CHECK(!(p.c_split || p.c2) || p.N % 32 == 0, "split32 outputs are whole 32-channel lines");
     const int ncols = p.N * (p.geglu ? 2 : 1);
     const int Nb = ncols;       // rows of B that exist
     int cfg;

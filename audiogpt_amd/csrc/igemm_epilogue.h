@@ -49,6 +49,22 @@ __device__ __forceinline__ void store_split1(float* row, int n, float v) {
     o[32] = __builtin_bit_cast(unsigned short, l);
 }
 
+// The same for the accumulator layout of the MFMA epilogues, where lane l holds column n = ... + (l & 31): the two lanes of an
+// even / odd column pair swap one half each (DPP quad_perm [1,0,3,2]) so that the even lane stores both hi halves and the odd
+// lane both lo halves -- ONE 4-byte store per lane and element instead of two 2-byte stores.  Both lanes of a pair must be
+// active (n even <-> lane even; callers guarantee N % 2 == 0 and a row condition that is uniform over the pair).
+__device__ __forceinline__ void store_split_pair(float* row, int n, float v) {
+    const __bf16 h = (__bf16)v;
+    const unsigned hb = __builtin_bit_cast(unsigned short, h);
+    const __bf16 l = (__bf16)(v - __builtin_bit_cast(float, hb << 16));
+    const unsigned lb = __builtin_bit_cast(unsigned short, l);
+    const bool even = (n & 1) == 0;
+    const unsigned mine = even ? lb : hb;                                  // what the partner stores
+    const unsigned theirs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);
+    unsigned* o = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(row) + (n >> 5) * 64 + ((n & 31) & ~1) + (even ? 0 : 32));
+    *o = even ? (hb | (theirs << 16)) : (theirs | (lb << 16));
+}
+
 // acc[MI][NI]: MI x NI fragments of 32x32 owned by this wave; (m_base, n_base) = first row / column of the wave.
 template <int MI, int NI>
 __device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI][NI], int m_base, int n_base,
@@ -84,7 +100,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI]
                             const int m = m_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                             if (m < p.M) {
                                 if (p.c_split)
-                                    store_split1(cp + (long long)m * p.ldc, ncol, outv[r]);
+                                    store_split_pair(cp + (long long)m * p.ldc, ncol, outv[r]);
                                 else
                                     cp[(long long)m * p.ldc + ncol] = outv[r];
                             }
@@ -162,12 +178,12 @@ __device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI]
                     const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lk;
                     if (m < p.M) {
                         if (p.c_split)
-                            store_split1(cp + (long long)m * p.ldc, n, outv[r]);
+                            store_split_pair(cp + (long long)m * p.ldc, n, outv[r]);
                         else
                             cp[(long long)m * p.ldc + n] = outv[r];
                         if (p.c2) {
                             const float w = outv[r] > 0.f ? outv[r] : outv[r] * p.c2_slope;
-                            store_split1(p.c2 + coff + (long long)m * p.ldc2, n, w);
+                            store_split_pair(p.c2 + coff + (long long)m * p.ldc2, n, w);
                         }
                     }
                 }

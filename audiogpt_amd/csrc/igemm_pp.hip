@@ -72,6 +72,7 @@ struct PPArgs {
     int NLp;             // A lines of one channel chunk: 256 + the last tap's offset, rounded up to a multiple of 16
     int CAPl;            // lines of the A ring (a multiple of 16, NLp + the host's margin .. 2 NLp)
     int ntiles, tiles;   // N tiles, M tiles x N tiles
+    int items;           // tiles x K slices
     int nci, cps;        // channel chunks in all, per K slice
     int Nb;              // rows of the packed weight that exist
     float* part;         // split-K slabs or null
@@ -104,22 +105,23 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     const int wm = wq / GWN, wn = wq - wm * GWN;
     const int lrow = lane & 31, lk = lane >> 5;
 
-    // ---- work item: (K slice, M tile, N tile), an XCD (block b runs on XCD b % 8) owns a contiguous range of items
-    int item;
+    // ---- work items: (K slice, M tile, N tile), q.items of them; an XCD (block b runs on XCD b % 8) owns a contiguous range
+    // and its workgroups walk it with a stride of their number.  A workgroup is persistent (the grid is capped at one per CU:
+    // the LDS holds one): it issues the first copies of its next item before the epilogue of the current one, so the cold
+    // start of an item hides under the stores of its predecessor (the vocoders' layers are 16 384 items of 12-44 chunks).
+    int w_lo, w_cnt, w_step;
     {
-        const int items = (int)gridDim.x, xcd = blockIdx.x & 7, qq = items >> 3, rr = items & 7;
-        item = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (int)(blockIdx.x >> 3);
+        const int G = (int)gridDim.x, xcd = blockIdx.x & 7, qq = q.items >> 3, rr = q.items & 7;
+        w_lo = xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
+        w_cnt = qq + (xcd < rr ? 1 : 0);
+        w_step = (G - xcd + 7) >> 3;
     }
-    // (the quotients are wave-uniform but come out of the VALU's division sequence: back into SGPRs)
-    const int slice = __builtin_amdgcn_readfirstlane(item / q.tiles), tile = item - slice * q.tiles;
-    const int mt = __builtin_amdgcn_readfirstlane(tile / q.ntiles), nt = tile - mt * q.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
-    const int c_begin = slice * q.cps;
-    const int c_end = min(q.nci, c_begin + q.cps);
+    int w_cur = (int)(blockIdx.x >> 3);
+    if (w_cur >= w_cnt) return;              // (never when grid <= items; uniform for the workgroup)
     const int TAPS = q.T;
-    const int NQ = (c_end - c_begin) * TAPS;
     const int W = q.W, H = q.H;
     const long long Mtot = p.M;
+    int item = 0, m0 = 0, n0 = 0, c_begin = 0, c_end = 0, NQ = 0;
 
     // zero line (read by lanes whose tap is outside the image)
     if (tid < 8) *reinterpret_cast<f32x4*>(sZ + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -130,19 +132,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     int a_r[MI];
     unsigned valid9[MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        a_r[i] = grp * 128 + wm * (32 * MI) + i * 32 + lrow;
-        const long long m = (long long)m0 + a_r[i];
-        unsigned v = 0;
-        if (m < Mtot) {
-            const int ox = (int)(m % W), oy = (int)((m / W) % H);
-            for (int t = 0; t < TAPS; ++t) {
-                const int iy = oy + (t / q.KW) * q.dh - q.ph, ix = ox + (t % q.KW) * q.dw - q.pw;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) v |= 1u << t;
-            }
-        }
-        valid9[i] = v;
-    }
+    for (int i = 0; i < MI; ++i) a_r[i] = grp * 128 + wm * (32 * MI) + i * 32 + lrow;
     const int lk16 = lk << 4;
     const unsigned zaddr = (unsigned)(sZ - smem);
     // B: row n of the slot at n * 128, slot swizzle by the row (tile offsets are multiples of 32 rows)
@@ -160,20 +150,46 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     const int r8 = lane >> 3, sl = lane & 7;
     // weights: this wave's pieces of a chunk are pb = grp BPG + k 4 + wq (k < NPB, existing while k 4 + wq < BPG)
     const char* gpb[NPB];
-#pragma unroll
-    for (int k = 0; k < NPB; ++k) {
-        const int pb = grp * BPG + k * 4 + wq;
-        const int nl = 8 * pb + r8;
-        const int n = min(n0 + nl, q.Nb - 1);          // rows past the last one: clamped, their columns are never stored
-        gpb[k] = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4);
-    }
     const int C4 = p.C1 * 4;                           // bytes between the taps of a weight row
     // A: during tap t of channel chunk c this wave issues pieces ((2 t + grp) 4 + wq) NPA + i of chunk c + 1
     const char* const a_base = reinterpret_cast<const char*>(p.a1);
     const unsigned lda4 = (unsigned)p.lda1 * 4u;      // bytes between positions (< 2^31)
     const int Mlast = p.M - 1;
-    const int a_P0 = m0 - q.padflat + r8;             // flat position of this lane's line of piece 0
+    int a_P0 = 0;                                     // flat position of this lane's line of piece 0
     const int a_pieces = q.NLp >> 3;
+    // per-item state: tile origin, K range, edge masks, weight row pointers
+    auto setup_item = [&](int w) __attribute__((always_inline)) {
+        item = w_lo + w;
+        // (the quotients are wave-uniform but come out of the VALU's division sequence: back into SGPRs)
+        const int slice = __builtin_amdgcn_readfirstlane(item / q.tiles), tile = item - slice * q.tiles;
+        const int mt = __builtin_amdgcn_readfirstlane(tile / q.ntiles), nt = tile - mt * q.ntiles;
+        m0 = mt * BM;
+        n0 = nt * BN;
+        c_begin = slice * q.cps;
+        c_end = min(q.nci, c_begin + q.cps);
+        NQ = (c_end - c_begin) * TAPS;
+        a_P0 = m0 - q.padflat + r8;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const long long m = (long long)m0 + a_r[i];
+            unsigned v = 0;
+            if (m < Mtot) {
+                const int ox = (int)(m % W), oy = (int)((m / W) % H);
+                for (int t = 0; t < TAPS; ++t) {
+                    const int iy = oy + (t / q.KW) * q.dh - q.ph, ix = ox + (t % q.KW) * q.dw - q.pw;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v |= 1u << t;
+                }
+            }
+            valid9[i] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NPB; ++k) {
+            const int pb = grp * BPG + k * 4 + wq;
+            const int nl = 8 * pb + r8;
+            const int n = min(n0 + nl, q.Nb - 1);          // rows past the last one: clamped, their columns are never stored
+            gpb[k] = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4);
+        }
+    };
     // any piece (prologue)
     auto issue_a_any = [&](int ci, int pa) __attribute__((always_inline)) {
         const int line = pa * 8 + r8;
@@ -182,29 +198,23 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + pa * 1024), 16, 0, 0);      // (the first chunk starts at line 0)
     };
 
-    // ---- prologue: A of the first chunk and the weights of chunks 0 and 1, by all eight waves
-    for (int pa = wid; pa < a_pieces; pa += 8) issue_a_any(c_begin, pa);
+    // first copies of the current item: A of its first chunk and the weights of chunks 0 and 1, by all eight waves
+    auto prologue = [&]() __attribute__((always_inline)) {
+        for (int pa = wid; pa < a_pieces; pa += 8) issue_a_any(c_begin, pa);
 #pragma unroll
-    for (int j = 0; j < NSB - 1; ++j) {
-        // (an item has at least T >= 3 chunks)
-        for (int pb = wid; pb < BN / 8; pb += 8) {
-            const int nl = 8 * pb + r8;
-            const int n = min(n0 + nl, q.Nb - 1);
-            const char* src = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4) +
-                              ((long long)j * C4 + (long long)c_begin * 128);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + j * (BN * 128) + pb * 1024), 16, 0, 0);
+        for (int j = 0; j < NSB - 1; ++j) {
+            // (an item has at least T >= 3 chunks)
+            for (int pb = wid; pb < BN / 8; pb += 8) {
+                const int nl = 8 * pb + r8;
+                const int n = min(n0 + nl, q.Nb - 1);
+                const char* src = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4) +
+                                  ((long long)j * C4 + (long long)c_begin * 128);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + j * (BN * 128) + pb * 1024), 16, 0, 0);
+            }
         }
-    }
-    wait_vmcnt<0>();
-    __syncthreads();
+    };
 
     f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     bf16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];      // [k-step][fragment]
 
@@ -212,10 +222,10 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     // the chunk whose weights are issued is two ahead: byte offset boff2 in a weight row, slot slot2, live while j + 2 < NQ
     // A ring: the chunk being read starts at line a_o, the next one at piece a_on8 (lines a_o + NLp, wrapped)
     const int cap8 = q.CAPl >> 3;
-    int a_o = 0, a_on8 = a_pieces >= cap8 ? a_pieces - cap8 : a_pieces;
-    int ci = c_begin, t = 0, kx = 0, shift = 0, slot = 0;
-    int slot2 = NSB - 1, t2 = NSB - 1;
-    long long boff2 = (long long)(NSB - 1) * C4 + (long long)c_begin * 128;
+    int a_o = 0, a_on8 = 0;
+    int ci = 0, t = 0, kx = 0, shift = 0, slot = 0;
+    int slot2 = 0, t2 = 0;
+    long long boff2 = 0;
 
     // memory phase of chunk j = (ci, t): fragments of the chunk into registers, this wave's pieces of chunk j + 2 and of
     // the next channel chunk's A on their way
@@ -322,43 +332,73 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         }
     };
 
-    // ---- ticks.  Group 1 runs one tick behind group 0; every wave passes 2 NQ barriers.
-    if (grp == 1) {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (int j = 0; j < NQ; ++j) {
-        load_phase(j);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (!TUNE || !(q.dbg & 1)) mma_phase();
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(grp == 1 && j == NQ - 1)) __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        advance();
-    }
-    wait_vmcnt<0>();        // (dummies only) nothing may land in LDS after the workgroup has given it back
-
-    // ---- epilogue or slab
-    const int rpb = p.Hout * p.Wout;
-    const int row_base = m0 + grp * 128 + wm * (32 * MI), col_base = n0 + wn * (32 * NI);
-    if (q.part == nullptr) {
-        igemm_epilogue<MI, NI>(p, acc, row_base, col_base, lrow, lk, 0, q.Nb, rpb);
-    } else {
-        // slab of this (slice, tile): [MI NI blocks][4 register quads][512 threads][4 floats]
-        float* pp = q.part + ((long long)item * (MI * NI * 4) * 512 + tid) * 4;
+    setup_item(w_cur);
+    prologue();
+    for (;;) {
+        wait_vmcnt<0>();
+        __syncthreads();                 // this item's first chunks are in LDS (and, first time, the zero line)
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int jn = 0; jn < NI; ++jn)
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int qd = 0; qd < 4; ++qd) {
-                    const f32x4 v = {acc[i][jn][4 * qd], acc[i][jn][4 * qd + 1], acc[i][jn][4 * qd + 2], acc[i][jn][4 * qd + 3]};
-                    *reinterpret_cast<f32x4*>(pp + (long long)((i * NI + jn) * 4 + qd) * 512 * 4) = v;
-                }
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        a_o = 0;
+        a_on8 = a_pieces;                // (the ring is longer than a chunk)
+        ci = c_begin;
+        t = kx = shift = slot = 0;
+        slot2 = t2 = NSB - 1;
+        boff2 = (long long)(NSB - 1) * C4 + (long long)c_begin * 128;
+
+        // ---- ticks.  Group 1 runs one tick behind group 0; every wave passes 2 NQ barriers.
+        if (grp == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int j = 0; j < NQ; ++j) {
+            load_phase(j);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!TUNE || !(q.dbg & 1)) mma_phase();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(grp == 1 && j == NQ - 1)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+        }
+        // Every fragment read of this item is done (a wave gets here through the barrier that follows group 1's last memory
+        // phase): the next item's first copies may overwrite the rings while this item's results are stored.
+        const int e_item = item, e_m0 = m0, e_n0 = n0;
+        const int w_next = w_cur + w_step;
+        const bool more = w_next < w_cnt;
+        if (more) {
+            setup_item(w_next);
+            prologue();
+        }
+
+        // ---- epilogue or slab
+        const int rpb = p.Hout * p.Wout;
+        const int row_base = e_m0 + grp * 128 + wm * (32 * MI), col_base = e_n0 + wn * (32 * NI);
+        if (q.part == nullptr) {
+            igemm_epilogue<MI, NI>(p, acc, row_base, col_base, lrow, lk, 0, q.Nb, rpb);
+        } else {
+            // slab of this (slice, tile): [MI NI blocks][4 register quads][512 threads][4 floats]
+            float* pp = q.part + ((long long)e_item * (MI * NI * 4) * 512 + tid) * 4;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const f32x4 v = {acc[i][jn][4 * qd], acc[i][jn][4 * qd + 1], acc[i][jn][4 * qd + 2], acc[i][jn][4 * qd + 3]};
+                        *reinterpret_cast<f32x4*>(pp + (long long)((i * NI + jn) * 4 + qd) * 512 * 4) = v;
+                    }
+        }
+        if (!more) break;
+        w_cur = w_next;
     }
+    wait_vmcnt<0>();        // (dummies only) nothing may land in LDS after the workgroup has given it back
 }
 
 // Tap geometry of a problem this engine takes (igemm_pp_plan checks eligibility)
@@ -443,11 +483,13 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     MAA_CHECK(q.CAPl > 0, "igemm_pp: the A ring does not fit beside the weight ring");
     const size_t lds = (size_t)q.CAPl * 128 + (size_t)NSB * BN * 128 + 128 + 1024;
     MAA_CHECK(lds <= 163840, "igemm_pp: LDS per workgroup");
-    const int items = q.tiles * pl.S;
+    q.items = q.tiles * pl.S;
+    const int cus = device_cu_count(ctx.device);
+    const int grid = q.items < cus ? q.items : cus;          // persistent: one workgroup per CU holds the LDS
     if (g.npa == 1)
-        launch_npa<MI, NI, GWM, GWN, 1>(ctx, p, q, items, lds);
+        launch_npa<MI, NI, GWM, GWN, 1>(ctx, p, q, grid, lds);
     else
-        launch_npa<MI, NI, GWM, GWN, 3>(ctx, p, q, items, lds);
+        launch_npa<MI, NI, GWM, GWN, 3>(ctx, p, q, grid, lds);
     if (pl.S > 1) launch_splitk_reduce(ctx, p, part, pl.S, q.tiles, ntiles, Nb, BM, BN, GWN, MI, NI, 512);
 }
 
