@@ -319,22 +319,25 @@ __global__ __launch_bounds__(NT, OCC) void flash_attn_kernel(const FlashArgs a) 
         }
     __syncthreads();
     float* op = a.out + b * a.o_bs + h * DH;
-    for (int i = lane; i < 32 * DH; i += 64) {
-        const int qi = i / DH, d = i - qi * DH;
-        if (q0 + qi < a.Nq) {
-            const float val = ot[qi * (DM + 1) + d];
-            if (a.out_split) {
+    if (a.out_split) {
+        // two neighbouring d per lane: one 4-byte store for the bf16 hi pair and one for the lo pair (h DH and d are even)
+        for (int i = lane; i < 16 * DH; i += 64) {
+            const int qi = i / (DH / 2), d = (i - qi * (DH / 2)) * 2;
+            if (q0 + qi < a.Nq) {
+                const float v0 = ot[qi * (DM + 1) + d], v1 = ot[qi * (DM + 1) + d + 1];
+                unsigned hi, lo;
+                split2(v0, v1, hi, lo);
                 const int c = h * DH + d;
                 unsigned short* o = reinterpret_cast<unsigned short*>(a.out + b * a.o_bs + (long long)(q0 + qi) * a.ldo) +
                                     (c >> 5) * 64 + (c & 31);
-                const __bf16 hv = (__bf16)val;
-                const unsigned short hb = __builtin_bit_cast(unsigned short, hv);
-                const __bf16 lv = (__bf16)(val - __builtin_bit_cast(float, (unsigned)hb << 16));
-                o[0] = hb;
-                o[32] = __builtin_bit_cast(unsigned short, lv);
-            } else {
-                op[(long long)(q0 + qi) * a.ldo + d] = val;
+                *reinterpret_cast<unsigned*>(o) = hi;
+                *reinterpret_cast<unsigned*>(o + 32) = lo;
             }
+        }
+    } else {
+        for (int i = lane; i < 32 * DH; i += 64) {
+            const int qi = i / DH, d = i - qi * DH;
+            if (q0 + qi < a.Nq) op[(long long)(q0 + qi) * a.ldo + d] = ot[qi * (DM + 1) + d];
         }
     }
 }

@@ -39,17 +39,8 @@ __device__ __forceinline__ float fast_erff(float x) {
 // the earlier rows, which turns a block's 16 stores into 16 dependent round trips.
 __device__ __forceinline__ void settle(float& x) { asm volatile("" : "+v"(x)); }
 
-// one output element in the split32 form (row pitch unchanged: every 32 columns = [32 bf16 hi | 32 bf16 lo])
-__device__ __forceinline__ void store_split1(float* row, int n, float v) {
-    unsigned short* o = reinterpret_cast<unsigned short*>(row) + (n >> 5) * 64 + (n & 31);
-    const __bf16 h = (__bf16)v;                                   // v_cvt_pk_bf16_f32, round to nearest even
-    const unsigned short hb = __builtin_bit_cast(unsigned short, h);
-    const __bf16 l = (__bf16)(v - __builtin_bit_cast(float, (unsigned)hb << 16));
-    o[0] = hb;
-    o[32] = __builtin_bit_cast(unsigned short, l);
-}
-
-// The same for the accumulator layout of the MFMA epilogues, where lane l holds column n = ... + (l & 31): the two lanes of an
+// An output element in the split32 form (row pitch unchanged: every 32 columns = [32 bf16 hi | 32 bf16 lo]), from the
+// accumulator layout of the MFMA epilogues, where lane l holds column n = ... + (l & 31): the two lanes of an
 // even / odd column pair swap one half each (DPP quad_perm [1,0,3,2]) so that the even lane stores both hi halves and the odd
 // lane both lo halves -- ONE 4-byte store per lane and element instead of two 2-byte stores.  Both lanes of a pair must be
 // active (n even <-> lane even; callers guarantee N % 2 == 0 and a row condition that is uniform over the pair).
@@ -66,9 +57,10 @@ __device__ __forceinline__ void store_split_pair(float* row, int n, float v) {
 }
 
 // acc[MI][NI]: MI x NI fragments of 32x32 owned by this wave; (m_base, n_base) = first row / column of the wave.
-template <int MI, int NI>
-__device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI][NI], int m_base, int n_base,
-                                               int lrow, int lk, long long coff, int Nb, int rpb) {
+// PAIR: plain fp32 output whose columns pair up (even width, even pitch, 8-byte aligned base): see the store loop
+template <int MI, int NI, bool PAIR>
+__device__ __forceinline__ void igemm_epilogue_impl(const IGemm& p, f32x16 (&acc)[MI][NI], int m_base, int n_base,
+                                                    int lrow, int lk, long long coff, int Nb, int rpb) {
     float* cp = p.c + coff;
     const float* resp = p.res ? p.res + coff : nullptr;
     if (p.geglu) {
@@ -173,23 +165,55 @@ __device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI]
                     if (p.accumulate && !p.c_split) v += cv[r];
                     outv[r] = v;
                 }
+                if constexpr (PAIR) {
+                    // fp32 rows, two columns per lane: the lanes of an even / odd column pair swap one value per pair of
+                    // rows (DPP), the even lane stores columns (n, n + 1) of the even row, the odd lane those of the odd row
+                    // -- 8 eight-byte stores per lane and block instead of 16 four-byte ones (the tail of these kernels is
+                    // store-issue-bound)
+                    const bool even = (lrow & 1) == 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (m < p.M) {
-                        if (p.c_split)
-                            store_split_pair(cp + (long long)m * p.ldc, n, outv[r]);
-                        else
-                            cp[(long long)m * p.ldc + n] = outv[r];
-                        if (p.c2) {
-                            const float w = outv[r] > 0.f ? outv[r] : outv[r] * p.c2_slope;
-                            store_split_pair(p.c2 + coff + (long long)m * p.ldc2, n, w);
+                    for (int rp = 0; rp < 8; ++rp) {
+                        const float keep = even ? outv[2 * rp] : outv[2 * rp + 1];
+                        const float give = even ? outv[2 * rp + 1] : outv[2 * rp];
+                        const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, false));
+                        const int r = 2 * rp + (even ? 0 : 1);
+                        const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        if (m < p.M) {
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            const f32x2 v2 = even ? f32x2{keep, got} : f32x2{got, keep};
+                            *reinterpret_cast<f32x2*>(cp + (long long)m * p.ldc + (n & ~1)) = v2;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        if (m < p.M) {
+                            if (p.c_split)
+                                store_split_pair(cp + (long long)m * p.ldc, n, outv[r]);
+                            else
+                                cp[(long long)m * p.ldc + n] = outv[r];
+                            if (p.c2) {
+                                const float w = outv[r] > 0.f ? outv[r] : outv[r] * p.c2_slope;
+                                store_split_pair(p.c2 + coff + (long long)m * p.ldc2, n, w);
+                            }
                         }
                     }
                 }
             }
         }
     }
+}
+
+template <int MI, int NI>
+__device__ __forceinline__ void igemm_epilogue(const IGemm& p, f32x16 (&acc)[MI][NI], int m_base, int n_base, int lrow,
+                                               int lk, long long coff, int Nb, int rpb) {
+    const bool pair = !p.no_pair && !p.geglu && !p.c_split && p.c2 == nullptr && (p.N & 1) == 0 && (p.ldc & 1) == 0 && (coff & 1) == 0 &&
+                      (reinterpret_cast<uintptr_t>(p.c) & 7) == 0;
+    if (pair)
+        igemm_epilogue_impl<MI, NI, true>(p, acc, m_base, n_base, lrow, lk, coff, Nb, rpb);
+    else
+        igemm_epilogue_impl<MI, NI, false>(p, acc, m_base, n_base, lrow, lk, coff, Nb, rpb);
 }
 
 }  // namespace maa

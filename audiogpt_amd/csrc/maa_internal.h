@@ -180,6 +180,7 @@ struct IGemm {
     float* c2 = nullptr;
     int ldc2 = 0;
     float c2_slope = 1.f;
+    int no_pair = 0;                 // MAA_NO_PAIR_STORE (A/B): plain 4-byte fp32 stores in the epilogue
     const float* zeros = nullptr;    // >= 16 B of zeros in device memory (filled in by launch_igemm)
     int m_fastest = 0;               // tile order inside an XCD's range: 1 = M-tiles fastest (MAA_TILE_ORDER=1: weights are
                                      // then fetched once chip-wide, but the conv's A re-reads lose their L2: +4 % step time)
