@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaudiogpt_mi355x.so")
+# AUDIOGPT_AMD_LIB: another build of the same library (same-box A/B of two builds; never a different implementation)
+LIB_PATH = os.environ.get("AUDIOGPT_AMD_LIB") or os.path.join(_HERE, "libaudiogpt_mi355x.so")
 
 
 class MaaError(RuntimeError):

@@ -94,11 +94,21 @@ __global__ __launch_bounds__(NT, OCC) void flash_attn_kernel(const FlashArgs a) 
         const int qrow = q0 + lq;
         const bool qok = qrow < a.Nq;
         const float* src = qp + (long long)(qok ? qrow : 0) * a.ldq;
+        // the softmax scale (and, on the exp2 path, log2 e) rides on Q: the scores leave the MFMA ready for the exponential
+        const float qs = a.precise_exp ? a.scale : a.scale * 1.4426950408889634f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d = ks * 16 + lh * 8;
-            const float4 x0 = *((qok && d < DH) ? reinterpret_cast<const float4*>(src + d) : zero4);
-            const float4 x1 = *((qok && d + 4 < DH) ? reinterpret_cast<const float4*>(src + d + 4) : zero4);
+            float4 x0 = *((qok && d < DH) ? reinterpret_cast<const float4*>(src + d) : zero4);
+            float4 x1 = *((qok && d + 4 < DH) ? reinterpret_cast<const float4*>(src + d + 4) : zero4);
+            x0.x *= qs;
+            x0.y *= qs;
+            x0.z *= qs;
+            x0.w *= qs;
+            x1.x *= qs;
+            x1.y *= qs;
+            x1.z *= qs;
+            x1.w *= qs;
             if constexpr (TERMS == 1) {
                 qh[ks].w[0] = pk_bf16(x0.x, x0.y);
                 qh[ks].w[1] = pk_bf16(x0.z, x0.w);
@@ -225,20 +235,30 @@ __global__ __launch_bounds__(NT, OCC) void flash_attn_kernel(const FlashArgs a) 
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, as_bf16x8(qh[ks]), sacc, 0, 0, 0);
         }
 
-        // ---- online softmax for query lq: this lane's keys are kt*32 + (r&3) + 8*(r>>2) + 4*lh
+        // ---- online softmax for query lq: this lane's keys are kt*32 + (r&3) + 8*(r>>2) + 4*lh.  The scores are already
+        // scaled (natural-log units on the precise path, log2 units on the exp2 path); only a short last tile or a causal
+        // mask needs the per-key test (uniform branch)
         float p[16];
         float mt = -INFINITY;
+        if (!a.causal && (kt + 1) * KT <= a.Nk) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * KT + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            p[r] = (key < a.Nk && (!a.causal || key <= q0 + lq)) ? sacc[r] * a.scale : -INFINITY;
-            mt = fmaxf(mt, p[r]);
+            for (int r = 0; r < 16; ++r) {
+                p[r] = sacc[r];
+                mt = fmaxf(mt, p[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * KT + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                p[r] = (key < a.Nk && (!a.causal || key <= q0 + lq)) ? sacc[r] : -INFINITY;
+                mt = fmaxf(mt, p[r]);
+            }
         }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        // exp through v_exp_f32 (exp2 of a pre-scaled argument, ~1 ulp): the softmax is the VALU-heavy part of this
-        // kernel; the running maximum settles after the first tiles, so the rescale of O is skipped for a wave whose
-        // lanes all kept their maximum (alpha == 1 exactly)
+        // exp through v_exp_f32 (~1 ulp): the softmax is the VALU-heavy part of this kernel; the running maximum settles
+        // after the first tiles, so the rescale of O is skipped for a wave whose lanes all kept their maximum (alpha == 1
+        // exactly)
         float alpha, ls = 0.f;
         if (a.precise_exp) {
             alpha = expf(m_run - m_new);                  // first tile: exp(-inf) = 0
@@ -248,12 +268,10 @@ __global__ __launch_bounds__(NT, OCC) void flash_attn_kernel(const FlashArgs a) 
                 ls += p[r];
             }
         } else {
-            constexpr float L2E = 1.4426950408889634f;
-            const float mb2 = m_new * L2E;
-            alpha = __builtin_amdgcn_exp2f(m_run * L2E - mb2);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(p[r] * L2E - mb2);
+                p[r] = __builtin_amdgcn_exp2f(p[r] - m_new);
                 ls += p[r];
             }
         }

@@ -58,7 +58,7 @@ __device__ __forceinline__ void store4(float* out, long long row, int c, int C, 
 // GroupNorm pass 1: one block per (sample, group) -> tab[(b*C + c)*2] = {scale, shift} for the group's channels
 // (scale = gamma*rstd, shift = beta - mean*scale, as ATen forms them); threads = (position
 // lane, channel-in-group).  One pass over the data: sums of d = x - pivot and d*d, with the group's first element as
-// pivot (so the subtraction var = E[d^2] - E[d]^2 cancels at most a couple of bits, like the two-pass form), four
+// pivot (so the subtraction var = E[d^2] - E[d]^2 cancels at most a couple of bits, like the two-pass form), eight
 // independent loads in flight per thread.  Fixed reduction order: results are bit-reproducible.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x1, int ld1, int C1,
                                                        const float* __restrict__ x2, int ld2, int C2, int HW,
@@ -84,27 +84,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     const int c0 = g * cpg;
     const float pivot = c0 < C1 ? x1[(long long)b * HW * ld1 + c0] : x2[(long long)b * HW * ld2 + (c0 - C1)];
     const float n = (float)HW * (float)cpg;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+    // eight independent loads in flight per thread: the pass is latency-bound (a 10 x 78 level is 31 positions per thread)
+    constexpr int U = 8;
+    float sa[U], qa[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sa[u] = qa[u] = 0.f;
     if (active) {
-        int pos = tp;
-        for (; pos + 3 * tp_n < HW; pos += 4 * tp_n) {
-            const float d0 = src[pos * ld] - pivot, d1 = src[(pos + tp_n) * ld] - pivot;
-            const float d2 = src[(pos + 2 * tp_n) * ld] - pivot, d3 = src[(pos + 3 * tp_n) * ld] - pivot;
-            s0 += d0;
-            s1 += d1;
-            s2 += d2;
-            s3 += d3;
-            q0 += d0 * d0;
-            q1 += d1 * d1;
-            q2 += d2 * d2;
-            q3 += d3 * d3;
-        }
-        for (; pos < HW; pos += tp_n) {
-            const float d0 = src[pos * ld] - pivot;
-            s0 += d0;
-            q0 += d0 * d0;
+        for (int pos = tp; pos < HW; pos += U * tp_n) {          // a position past the end reads as the pivot: d = 0
+            float d[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pu = pos + u * tp_n;
+                d[u] = pu < HW ? src[(long long)pu * ld] : pivot;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                d[u] -= pivot;
+                sa[u] += d[u];
+                qa[u] += d[u] * d[u];
+            }
         }
     }
+    const float s0 = sa[0] + sa[4], s1 = sa[1] + sa[5], s2 = sa[2] + sa[6], s3 = sa[3] + sa[7];
+    const float q0 = qa[0] + qa[4], q1 = qa[1] + qa[5], q2 = qa[2] + qa[6], q3 = qa[3] + qa[7];
     const float sm = block_sum((s0 + s1) + (s2 + s3), red) / n;
     const float qm = block_sum((q0 + q1) + (q2 + q3), red) / n;
     if (threadIdx.x == 0) {

@@ -123,7 +123,8 @@ def test_conv_transpose1d(ctx, Cin, Cout, k, s, L):
 
 
 @pytest.mark.parametrize("C,HW,eps,silu", [(320, 780, 1e-5, True), (960, 195, 1e-5, True), (1280, 195, 1e-6, False),
-                                           (128, 4096, 1e-6, True), (512, 780, 1e-6, False), (32, 50, 1e-5, True)])
+                                           (128, 4096, 1e-6, True), (512, 780, 1e-6, False), (32, 50, 1e-5, True),
+                                           (64, 1003, 1e-5, False), (1920, 780, 1e-5, True)])
 def test_groupnorm(ctx, C, HW, eps, silu):
     x = torch.randn(2, C, HW, generator=g(28)) * 2.0 + 0.5
     ga = torch.randn(C, generator=g(29))
