@@ -694,15 +694,6 @@ int maa_op_bench_conv(maa_ctx* ctx, int B, int H, int W, int Cin, int Cout, int 
                 }
             hx.swap(packed);
         }
-        int x_ld = 0;
-        static const int apad = std::getenv("MAA_APAD") ? std::atoi(std::getenv("MAA_APAD")) : 0;   // experiment
-        if (apad > 0) {
-            std::vector<float> pitched((size_t)B * H * W * (Cin + apad), 0.f);
-            for (size_t r = 0; r < (size_t)B * H * W; ++r)
-                std::memcpy(&pitched[r * (Cin + apad)], &hx[r * Cin], sizeof(float) * Cin);
-            hx.swap(pitched);
-            x_ld = Cin + apad;
-        }
         float* dx = ws.upload(hx);
         float* dy = ws.upload(std::vector<float>(n_out, 0.f));
         maa::T4 x, y;
@@ -712,7 +703,6 @@ int maa_op_bench_conv(maa_ctx* ctx, int B, int H, int W, int Cin, int Cout, int 
         x.C = Cin;
         y.C = Cout;
         x.p = dx;
-        x.ld = x_ld;
         y.p = dy;
         if (pre_split && c.dtype != 0) {
             x.split = true;

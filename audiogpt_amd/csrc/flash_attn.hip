@@ -60,9 +60,9 @@ struct Frag {      // 8 bf16 = 4 dwords, bit-castable to the MFMA operand type
 };
 __device__ __forceinline__ bf16x8 as_bf16x8(const Frag& f) { return __builtin_bit_cast(bf16x8, f); }
 
-// OCC: workgroups per CU the register allocation must allow (1 = whatever the kernel needs)
-template <int DH, int TERMS, int OCC>
-__global__ __launch_bounds__(NT, OCC) void flash_attn_kernel(const FlashArgs a) {
+// (capping the d = 40 kernel at 128 VGPRs -- four workgroups per CU -- spills and is 20 % slower: DESIGN.md 3.3)
+template <int DH, int TERMS>
+__global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
     constexpr int DK = (DH + 15) / 16 * 16;      // head dim padded to the MFMA k-step
     constexpr int DM = (DH + 31) / 32 * 32;      // rows of O^T
     constexpr int KS = DK / 16, MB = DM / 32;
@@ -360,13 +360,13 @@ __global__ __launch_bounds__(NT, OCC) void flash_attn_kernel(const FlashArgs a) 
     }
 }
 
-template <int DH, int TERMS, int OCC = 1>
+template <int DH, int TERMS>
 void launch_dh(const Ctx& ctx, const FlashArgs& a, int B) {
     constexpr int DK = (DH + 15) / 16 * 16, DM = (DH + 31) / 32 * 32, PL = TERMS == 1 ? 1 : 2;
     constexpr size_t kv = (size_t)2 * PL * (KT * (DK + 8) + DM * (KT + 4)) * sizeof(unsigned short);
     constexpr size_t tr = (size_t)4 * 32 * (DM + 1) * sizeof(float);
     constexpr size_t lds = kv > tr ? kv : tr;
-    auto kern = flash_attn_kernel<DH, TERMS, OCC>;
+    auto kern = flash_attn_kernel<DH, TERMS>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     dim3 grid((unsigned)((a.Nq + 127) / 128), (unsigned)(B * a.heads));
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, a);
@@ -415,12 +415,6 @@ bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, co
     const double bytes = 4.0 * B * heads * ((double)2 * Nq * dh + 2.0 * Nk * dh);
     ProfScope prof(ctx, "flash_attention", flops, bytes);
     const int terms = ctx.dtype == 1 ? 3 : 1;
-    static const bool occ4 = std::getenv("MAA_FLASH_OCC4") != nullptr;      // A/B: d = 40 capped at 128 VGPRs (4 workgroups per CU)
-    if (occ4 && dh == 40 && terms == 3) {
-        launch_dh<40, 3, 4>(ctx, a, B);
-        MAA_HIP(hipGetLastError());
-        return true;
-    }
 #define MAA_FLASH(DHV)                                 \
     if (terms == 3)                                    \
         launch_dh<DHV, 3>(ctx, a, B);                  \

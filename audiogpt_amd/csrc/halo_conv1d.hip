@@ -280,17 +280,15 @@ bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, con
     a.dil = dil;
     a.slope = slope;
     // tile length: 256 positions at C = 32 (56 KB of LDS, two workgroups per CU); 128 at C = 64 (80 KB: still two per CU, so
-    // one workgroup's tile staging overlaps the other's MFMAs; 256 would be 112 KB and one per CU).  MAA_HALO_TL64=256: A/B.
-    static const int tl64 = std::getenv("MAA_HALO_TL64") ? std::atoi(std::getenv("MAA_HALO_TL64")) : 128;
-    const int TLr = C == 32 ? 256 : (tl64 == 256 ? 256 : 128);
+    // one workgroup's tile staging overlaps the other's MFMAs; 256 would be 112 KB and one per CU, and measured slower:
+    // profiles/r2_halo_conv1d_variants.txt)
+    const int TLr = C == 32 ? 256 : 128;
     a.tiles_per_sample = (L + TLr - 1) / TLr;
     a.tiles = B * a.tiles_per_sample;
     const double flops = 2.0 * B * (double)L * C * (double)C * k;
     ProfScope prof(ctx, C == 32 ? "halo_conv1d_bf16x3<32>" : "halo_conv1d_bf16x3<64>", flops, 12.0 * B * (double)L * C);
     if (C == 32)
         launch_c<32, 256, 4>(ctx, a);
-    else if (TLr == 256)
-        launch_c<64, 256, 4>(ctx, a);
     else
         launch_c<64, 128, 4>(ctx, a);
     MAA_HIP(hipGetLastError());

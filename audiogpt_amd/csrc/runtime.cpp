@@ -252,8 +252,7 @@ void WeightStore::finish(PackedW& pw, const std::vector<float>& kn, bool bf16_ok
         // pre-split "split32" rows [Npad][K]: every 32 k of a row are one 128-byte line [32 hi | 32 lo] with
         // hi = bf16(w), lo = bf16(w - hi); the kernel copies the lines straight to LDS.  ld is in fp32 units.
         MAA_CHECK(pw.K % 32 == 0, "split32 weights need K % 32 == 0");
-        static const int wpad = std::getenv("MAA_WPAD") ? std::atoi(std::getenv("MAA_WPAD")) : 0;   // experiment
-        const int ldk = pw.K + wpad;
+        const int ldk = pw.K;
         std::vector<unsigned short> t((size_t)pw.Npad * ldk * 2, 0);
         for (int k = 0; k < pw.K; ++k)
             for (int n = 0; n < pw.Npad; ++n) {

@@ -176,6 +176,75 @@ def hifigan64_mel(B=HIFIGAN64["B"], T=HIFIGAN64["T"], seed=HIFIGAN64["seed"]):
     return torch.clamp(torch.randn(B, 80, T, generator=g) * 1.5 - 2.25, -6.0, 1.5)
 
 
+class BoxSampler:
+    """Best-effort record of what the GPU ran at during the timed region: a thread reads the amdgpu sysfs nodes of one card
+    (current shader clock level of pp_dpm_sclk, socket power of its hwmon) twice a second.  Box-to-box spread of one binary is
+    several percent and follows the clock a box sustains under this load; nothing here is required --
+    every failure yields None."""
+
+    def __init__(self, root="/sys/class/drm", period=0.5):
+        import glob
+        import threading
+        self.sclk, self.power, self.period = [], [], period
+        self._stop = threading.Event()
+        self._thread = None
+        self.card = None
+        for c in sorted(glob.glob(os.path.join(root, "card[0-9]*"))):
+            if os.path.exists(os.path.join(c, "device", "pp_dpm_sclk")):
+                self.card = os.path.join(c, "device")
+                break
+        self._hw = sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*"))) if self.card else []
+
+    @staticmethod
+    def parse_sclk(text):
+        """MHz of the level pp_dpm_sclk marks with '*' (None if there is none)."""
+        import re
+        for line in text.splitlines():
+            if line.rstrip().endswith("*"):
+                m = re.search(r"(\d+)\s*mhz", line.lower())
+                if m:
+                    return int(m.group(1))
+        return None
+
+    def sample(self):
+        try:
+            v = self.parse_sclk(open(os.path.join(self.card, "pp_dpm_sclk")).read())
+            if v is not None:
+                self.sclk.append(v)
+        except Exception:
+            pass
+        for h in self._hw:
+            for f in ("power1_average", "power1_input"):
+                try:
+                    self.power.append(int(open(os.path.join(h, f)).read().strip()) / 1e6)     # microwatts
+                    return
+                except Exception:
+                    continue
+
+    def __enter__(self):
+        import threading
+        if self.card:
+            def loop():
+                while not self._stop.wait(self.period):
+                    self.sample()
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+        return False
+
+    def summary(self):
+        def med(v):
+            return sorted(v)[len(v) // 2] if v else None
+        return {"sclk_mhz_median": med(self.sclk), "sclk_mhz_min": min(self.sclk) if self.sclk else None,
+                "socket_power_w_median": med(self.power), "samples": len(self.sclk),
+                "source": "amdgpu sysfs (pp_dpm_sclk, hwmon power) of %s, sampled during the timed region" % self.card}
+
+
 def roofline_of(rows, precision):
     """Roofline object of the dominant implicit-GEMM kernel out of a maa_prof table (hipEvents on the library's stream)."""
     total_ms = sum(r["ms"] for r in rows.values())
@@ -540,10 +609,15 @@ def main(argv=None):
     barrier()
     for v in comm_events.values():
         v.clear()
+    sampler = BoxSampler() if (rank == 0 and not stub) else None
+    if sampler is not None:
+        sampler.__enter__()
     t0 = time.perf_counter()
     out = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    if sampler is not None:
+        sampler.__exit__()
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -571,6 +645,8 @@ def main(argv=None):
         # Little's law for the overlapped arrangement: `inflight` batches are resident for `inflight` throughput periods
         "batch_latency_ms": {"in_flight": 1000.0 * elapsed / args.steps * inflight},
     }
+    if sampler is not None:
+        result["box"] = sampler.summary()
 
     if rank == 0 and not args.no_roofline:
         # one more batch, eager (graph launches cannot be event-timed), every kernel bracketed by hipEvents on the

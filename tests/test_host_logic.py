@@ -158,15 +158,20 @@ def test_pmc_traffic_derivation_and_staleness_guard(tmp_path):
 
 
 def test_bench_line_contract_of_a_gpu_run():
-    """A bench line measured on the MI355X this round (profiles/r2_bf16x3_bench.json, written by scripts/gpu_profile.sh)
-    carries every field of the driver's contract plus roofline, cpu_baseline and the secondary workloads, and its
-    arithmetic is self-consistent."""
+    """A bench line measured on the MI355X this round (profiles/r3_bf16x3_bench.json, written by scripts/gpu_profile.sh)
+    carries every field of the driver's contract plus roofline, cpu_baseline and the secondary workloads, states its method
+    in the metric string, and its arithmetic is self-consistent."""
     import json
-    path = os.path.join(ROOT, "profiles", "r2_bf16x3_bench.json")
+    path = os.path.join(ROOT, "profiles", "r3_bf16x3_bench.json")
     if not os.path.exists(path):
         import pytest
-        pytest.skip("no round-2 bench line committed yet")
+        pytest.skip("no round-3 bench line committed yet")
     d = json.load(open(path))
+    assert "batches of 8 prompts in flight per GPU" in d["metric"] and d["config"]["batches_in_flight"] == 3
+    assert d["one_batch_in_flight"]["value"] > 0 and d["batch_latency_ms"]["in_flight"] > d["batch_latency_ms"]["alone"] > 0
+    for w in ("hifigan64", "mixed"):
+        sec = d["secondary"][w]
+        assert sec["value"] > 0 and sec["cpu_baseline"]["value"] > 0 and 0 < sec["roofline"]["frac"] < 1
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -177,6 +182,28 @@ def test_bench_line_contract_of_a_gpu_run():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
     assert abs(d["value"] - d["config"]["audio_seconds_per_step"] / (d["ms_per_step"] / 1e3)) < 1e-6 * d["value"]
+
+
+def test_bench_box_sampler_reads_amdgpu_sysfs(tmp_path):
+    """bench.BoxSampler (clock / power of the box during the timed region) against a fake sysfs tree, and on a machine with
+    no such tree (this container): it never raises and reports None."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.BoxSampler.parse_sclk("0: 132Mhz\n1: 2242Mhz *\n") == 2242
+    assert bench.BoxSampler.parse_sclk("S: 95Mhz *") == 95 and bench.BoxSampler.parse_sclk("0: 132Mhz\n") is None
+    dev = tmp_path / "card0" / "device"
+    (dev / "hwmon" / "hwmon3").mkdir(parents=True)
+    (dev / "pp_dpm_sclk").write_text("0: 132Mhz\n1: 2230Mhz *\n")
+    (dev / "hwmon" / "hwmon3" / "power1_average").write_text("1350000000\n")
+    with bench.BoxSampler(root=str(tmp_path), period=0.02) as sm:
+        time.sleep(0.2)
+    r = sm.summary()
+    assert r["sclk_mhz_median"] == 2230 and r["sclk_mhz_min"] == 2230 and abs(r["socket_power_w_median"] - 1350.0) < 1e-6 and r["samples"] >= 2
+    with bench.BoxSampler(root=str(tmp_path / "nothing")) as sm:
+        pass
+    assert sm.summary()["sclk_mhz_median"] is None and sm.summary()["samples"] == 0
 
 
 def test_mel_front_end_restatement():
