@@ -472,6 +472,9 @@ def main(argv=None):
     ap.add_argument("--legacy-streams", action="store_true",
                     help="replicas on library-created blocking streams (ordered against PyTorch's default stream) instead of one "
                          "private torch stream each")
+    ap.add_argument("--stagger-ms", type=float, default=0.0,
+                    help="replica k waits k x this long before its first batch of a run (A/B: do the replicas' DDIM steps overlap "
+                         "better out of phase?)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="prompt batches in flight per GPU: consecutive steps (independent batches of 8 prompts) run on this many "
                          "pipeline replicas / HIP streams, as a serving loop would overlap requests; 1 = strictly one after another")
@@ -550,11 +553,16 @@ def main(argv=None):
     x_T = start_codes(55, n * world, LATENT, world, rank).to(dev)
     cond_shape, counts = (n * world, 77, 1024), [n] * world
 
-    def make_generator(p_):
+    def make_generator(p_, k_=0):
+        first = [args.stagger_ms > 0 and k_ > 0]
+
         def generate(c_, uc_, ready):
             """One prompt batch on replica p_ (worker thread): everything on the replica's own stream, after the event the
             main thread recorded behind this batch's conditioning; returns the waveforms and the event that marks them done."""
             done = Event()
+            if first[0]:
+                first[0] = False
+                time.sleep(k_ * args.stagger_ms * 1e-3)
             if p_.stream is None:
                 wav = p_.generate_here(x_T, c_, uc_, CFG_SCALE, S, use_graph=use_graph)[0]
                 done.record(None if stub else torch.cuda.current_stream(dev))
@@ -596,7 +604,7 @@ def main(argv=None):
     def run_steps(k):
         """k steps; step i runs on pipeline i % inflight while the previous inflight-1 steps are still sampling
         (audiogpt_amd.shard.run_in_flight: collectives on this thread, in step order)."""
-        outs = run_in_flight(k, [make_generator(p_) for p_ in pipes], conditioning, gather, pool)
+        outs = run_in_flight(k, [make_generator(p_, k_) for k_, p_ in enumerate(pipes)], conditioning, gather, pool)
         return outs[-1] if outs else None
 
     def barrier():
