@@ -1,0 +1,137 @@
+"""ISA-level guards on the hot kernels, checked on the cross-compiled gfx950 assembly (no GPU needed): the properties the
+performance analysis in DESIGN.md section 3 rests on.
+
+  * every contraction engine's K loop issues MFMAs and touches no scratch memory (register spills, where a kernel has them,
+    stay in the per-item prologue / epilogue);
+  * the LDS-DMA engines really copy with `global_load_lds` (no register staging), the bf16x3 engines use the
+    32x32x16 bf16 MFMA, the exact mode the 32x32x2 fp32 one;
+  * no kernel needs more registers than two waves per SIMD allow where the schedule depends on it.
+"""
+import os
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "audiogpt_amd", "csrc")
+FILES = ["igemm_pp.hip", "igemm_dma.hip", "igemm_dma2.hip", "igemm_bf16.hip", "igemm_f32.hip", "flash_attn.hip", "halo_conv1d.hip"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def _assemble(name, outdir):
+    from audiogpt_amd.build import FLAGS
+    out = os.path.join(outdir, name + ".s")
+    flags = [f for f in FLAGS if f != "-fPIC"]
+    cmd = [_hipcc()] + flags + ["--cuda-device-only", "-S", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+                               os.path.join(CSRC, name), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read()
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if _hipcc() is None:
+        pytest.skip("hipcc not found")
+    d = str(tmp_path_factory.mktemp("isa"))
+    with ThreadPoolExecutor(max_workers=min(len(FILES), os.cpu_count() or 1)) as ex:
+        texts = list(ex.map(lambda f: _assemble(f, d), FILES))
+    return dict(zip(FILES, texts))
+
+
+def kernels(text):
+    """{mangled name: list of body lines} for every kernel of an assembly file."""
+    lines = text.split("\n")
+    out = {}
+    i = 0
+    while i < len(lines):
+        m = re.match(r"^(_Z\w+):", lines[i])
+        if m:
+            j = i + 1
+            while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+                j += 1
+            out[m.group(1)] = lines[i:j]
+            i = j
+        i += 1
+    return out
+
+
+def loops(body):
+    """(start, end) line ranges closed by a backward branch."""
+    labels = {l.split(":")[0]: i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+    res = []
+    for i, l in enumerate(body):
+        m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and labels[m.group(1)] < i:
+            res.append((labels[m.group(1)], i))
+    return res
+
+
+def mfma_loops_without_scratch(body):
+    """For the INNERMOST loops that contain MFMAs: (number of such loops, number of them that touch scratch)."""
+    ls = [(a, b) for a, b in loops(body) if any("v_mfma" in x for x in body[a:b + 1])]
+    inner = [(a, b) for a, b in ls if not any((c, d) != (a, b) and a <= c and d <= b for c, d in ls)]
+    bad = [(a, b) for a, b in inner if any("scratch_" in x for x in body[a:b + 1])]
+    return len(inner), len(bad)
+
+
+def test_no_scratch_inside_any_mfma_loop(asm):
+    seen = 0
+    for f, text in asm.items():
+        for name, body in kernels(text).items():
+            if not any("v_mfma" in l for l in body):
+                continue
+            if f == "igemm_pp.hip" and "Lb1EEEv" in name:
+                continue      # TUNE = true: the ablation build (MAA_PP_DBG), timing only, never selected by default
+            if f == "igemm_f32.hip" and "ILi128ELi128ELi2ELi2ELb0E" in name:
+                # KNOWN, exact-fp32 mode only: the unaligned-operand path of the 128x128 tile indexes its staging registers
+                # at run time, which puts them in an 80-byte stack slot (8 scratch instructions per 64 MFMAs).  Not on the
+                # benchmark's path (bf16x3); listed in DESIGN.md section 8.
+                continue
+            n, bad = mfma_loops_without_scratch(body)
+            assert n >= 1, (f, name, "MFMAs outside any loop only")
+            assert bad == 0, (f, name, "scratch traffic inside a K loop")
+            seen += 1
+    assert seen >= 20      # every instantiation of every engine was looked at
+
+
+def test_engines_use_the_instructions_the_design_names(asm):
+    def count(f, pat):
+        return len(re.findall(pat, asm[f]))
+    for f in ("igemm_pp.hip", "igemm_dma.hip", "igemm_dma2.hip", "halo_conv1d.hip"):
+        assert count(f, r"global_load_lds_dwordx4|global_load_lds") > 0, f
+        assert count(f, r"v_mfma_f32_32x32x16_bf16") > 0, f
+    assert count("igemm_bf16.hip", r"v_mfma_f32_32x32x16_bf16") > 0 and count("igemm_bf16.hip", r"global_load_lds") == 0
+    assert count("igemm_f32.hip", r"v_mfma_f32_32x32x2_f32") > 0
+    assert count("flash_attn.hip", r"v_mfma_f32_32x32x16_bf16") > 0 and count("flash_attn.hip", r"v_exp_f32") > 0
+    # the ping-pong engines synchronise with raw barriers and counted waits, not __syncthreads' full drain
+    assert count("igemm_pp.hip", r"s_barrier") > 0 and count("igemm_pp.hip", r"s_waitcnt vmcnt\(\d+\)") > 0
+
+
+def test_register_budgets(asm):
+    """Two waves per SIMD (the ping-pong schedule) need <= 256 VGPRs; the d = 40 flash-attention kernel must leave room for three
+    workgroups per CU (<= 168).  Spills are allowed only where DESIGN.md 3.2b says they are: the 160-wide ping-pong instantiations."""
+    meta = {}
+    for f, text in asm.items():
+        for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text):
+            meta[(f, m.group(1))] = (int(m.group(2)), int(m.group(3)))
+    assert len(meta) >= 20
+    for (f, name), (vg, spill) in meta.items():
+        if f == "igemm_pp.hip":
+            assert vg <= 256, (name, vg)
+            if "Li1ELi5E" not in name and "Lb1EEEv" not in name:      # not the 160-wide tile, not the tuning build
+                assert spill == 0, (name, spill)
+        elif f == "flash_attn.hip":
+            assert spill == 0, (name, spill)
+            if "ILi40ELi3E" in name:          # the 780-token self-attention: 896 workgroups want three per CU
+                assert vg <= 168, (name, vg)
+        else:
+            assert spill == 0, (f, name, spill)
