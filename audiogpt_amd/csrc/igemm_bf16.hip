@@ -340,6 +340,7 @@ void launch_tile(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
         case 0: launch_one<128, 128, 2, 2, TERMS, AS, BS, BKT, 2>(ctx, p, Nb); break;
         case 1: launch_one<128, 64, 2, 2, TERMS, AS, BS, BKT, 2>(ctx, p, Nb); break;
         case 2: launch_one<64, 64, 2, 2, TERMS, AS, BS, BKT, 2>(ctx, p, Nb); break;
+        case 4: launch_one<128, 32, 4, 1, TERMS, AS, BS, BKT, 2>(ctx, p, Nb); break;
         default: launch_one<256, 32, 4, 1, TERMS, AS, BS, BKT, 2>(ctx, p, Nb); break;
     }
 }
@@ -399,12 +400,14 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         if (ncols % 64 != 0) return false;
         cfg = 0;
     } else if (ncols <= 32) {
-        cfg = 3;
+        // 256-row tiles; 128-row ones while those would leave most of the chip idle (the UNet's 320 -> 4 output convolution:
+        // 49 workgroups of 90 chunks each).  No K split either way: the two tiles give bit-identical results.
+        cfg = (long long)((p.M + 255) / 256) * p.Z < 128 ? 4 : 3;
     } else {
         cfg = choose_tile(p.M, ncols, p.Z, true);
     }
     static const bool no_dma = std::getenv("MAA_NO_DMA") != nullptr;      // tests: same arithmetic, register staging
-    const bool dma = terms == 3 && p.a_split && p.b_split && cfg != 3 && !no_dma;
+    const bool dma = terms == 3 && p.a_split && p.b_split && cfg < 3 && !no_dma;
     const PPPlan planp = dma ? igemm_pp_plan(ctx, p) : PPPlan();
     if (planp.bn) {
         // halo-staged ping-pong engine for the 3x3 convolutions (igemm_pp.hip); slabs borrowed like the second engine's
@@ -472,8 +475,8 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     const double flops = 2.0 * p.M * (double)ncols * p.K * p.Z;
     const double bytes = 4.0 * ((double)p.K * ncols + (double)p.M * p.N * p.Z);
     static const char* kNamesD[3] = {"igemm_dma_bf16x3<128x128>", "igemm_dma_bf16x3<128x64>", "igemm_dma_bf16x3<64x64>"};
-    static const char* kNames3[4] = {"igemm_bf16x3<128x128>", "igemm_bf16x3<128x64>", "igemm_bf16x3<64x64>", "igemm_bf16x3<256x32>"};
-    static const char* kNames1[4] = {"igemm_bf16<128x128>", "igemm_bf16<128x64>", "igemm_bf16<64x64>", "igemm_bf16<256x32>"};
+    static const char* kNames3[5] = {"igemm_bf16x3<128x128>", "igemm_bf16x3<128x64>", "igemm_bf16x3<64x64>", "igemm_bf16x3<256x32>", "igemm_bf16x3<128x32>"};
+    static const char* kNames1[5] = {"igemm_bf16<128x128>", "igemm_bf16<128x64>", "igemm_bf16<64x64>", "igemm_bf16<256x32>", "igemm_bf16<128x32>"};
     char shape_name[48];
     const char* pname = dma ? kNamesD[cfg] : terms == 3 ? kNames3[cfg] : kNames1[cfg];
     if (ctx.prof && ctx.prof->detail) {

@@ -276,8 +276,14 @@ void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
     // Round 2: the long-K contractions moved to igemm_dma2.hip; on what is left to the 64x64 tile (K = 320 / 640 linears,
     // ten or twenty chunks) two stages -- five workgroups per CU instead of two -- win: in-pipeline (2,3,2) -2.3 % vs (2,3,4)
     // (profiles/r2_dma2_inpipe_probes.txt).
-    const int ns = ns_env ? ns_env : (cfg == 2 ? 2 : cfg == 1 ? 3 : 2);
-    (void)ncols;
+    int ns = ns_env ? ns_env : (cfg == 2 ? 2 : cfg == 1 ? 3 : 2);
+    // Round 4: a 64x64 launch that puts fewer than ~2.5 workgroups on a CU (the K = 640 linears of the 5 x 39 level: 490 tiles
+    // of 20 chunks) has one 16 KB chunk in flight per workgroup and waits ~1 us for each -- latency-, not fill-bound; such
+    // launches take the deeper queue (MAA_DMA_NS_LOW, parsed with the context's tuning; 0 keeps two stages everywhere).
+    if (!ns_env && cfg == 2 && ctx.tune.dma_ns_low > 2) {
+        const long long tiles = (long long)((p.M + 63) / 64) * ((ncols + 63) / 64);
+        if (tiles * 2 < 5LL * device_cu_count(ctx.device)) ns = ctx.tune.dma_ns_low;
+    }
     switch (cfg) {
         case 0:
             if (ns >= 3) launch_one<128, 128, 2, 2, 3>(ctx, p, Nb);

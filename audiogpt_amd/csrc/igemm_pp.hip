@@ -82,7 +82,12 @@ struct PPArgs {
 // MI x NI fragments of 32x32 per wave; a group's 128 x BN block is GWM x GWN waves (GWM GWN = 4, GWM 32 MI = 128)
 // NPA: A pieces a wave issues per memory phase (1 for 3x3 / long 1-D kernels, 3 for the 3-tap 1-D kernels whose next chunk
 // has only two taps' worth of phases to arrive in)
-template <int MI, int NI, int GWM, int GWN, int NPA, bool TUNE>
+// PERSIST = false: a launch whose grid covers every item (the UNet's: 196-208 items on 256 CUs) -- the epilogue does not carry
+// the next item's staging state, which is what made the 256 x 160 instantiation spill 81 VGPRs
+// OUT: 0 = the result leaves through the fused epilogue or as a split-K slab (run-time choice; the TUNE build), 1 = epilogue
+// only, 2 = slab only -- the UNet's launches are all of the last kind, and an instantiation without the epilogue's registers
+// has no scratch at all
+template <int MI, int NI, int GWM, int GWN, int NPA, bool TUNE, bool PERSIST, int OUT>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPArgs q) {
     constexpr int BN = GWN * NI * 32;
     constexpr int BPG = BN / 16;                    // weight pieces (8 rows x 128 B) per group and chunk: half a chunk
@@ -371,16 +376,19 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         // phase): the next item's first copies may overwrite the rings while this item's results are stored.
         const int e_item = item, e_m0 = m0, e_n0 = n0;
         const int w_next = w_cur + w_step;
-        const bool more = w_next < w_cnt;
-        if (more) {
-            setup_item(w_next);
-            prologue();
+        bool more = false;
+        if constexpr (PERSIST) {
+            more = w_next < w_cnt;
+            if (more) {
+                setup_item(w_next);
+                prologue();
+            }
         }
 
         // ---- epilogue or slab
         const int rpb = p.Hout * p.Wout;
         const int row_base = e_m0 + grp * 128 + wm * (32 * MI), col_base = e_n0 + wn * (32 * NI);
-        if (q.part == nullptr) {
+        if (OUT == 1 || (OUT == 0 && q.part == nullptr)) {
             igemm_epilogue<MI, NI>(p, acc, row_base, col_base, lrow, lk, 0, q.Nb, rpb);
         } else {
             // slab of this (slice, tile): [MI NI blocks][4 register quads][512 threads][4 floats]
@@ -442,14 +450,20 @@ int pp_ring_lines(const PPGeom& g, int bn) {
 template <int MI, int NI, int GWM, int GWN, int NPA>
 void launch_npa(const Ctx& ctx, const IGemm& p, const PPArgs& q, int items, size_t lds) {
     if (ctx.tune.pp_dbg >= 0) {      // timing ablations (MAA_PP_DBG): a separate instantiation, never the product's
-        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, NPA, true>;
+        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, NPA, true, true, 0>;
         ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
         hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
-    } else {
-        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false>;
-        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
-        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
+        return;
     }
+    auto go = [&](auto kern) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
+        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
+    };
+    const bool persist = q.items > items, slab = q.part != nullptr;      // (more items than workgroups: persistent)
+    if (persist && slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 2>);
+    else if (persist) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 1>);
+    else if (slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, false, 2>);
+    else go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, false, 1>);
 }
 
 template <int MI, int NI, int GWM, int GWN>

@@ -120,6 +120,8 @@ struct Tuning {
     std::string pp, pp1;                    // MAA_PP / MAA_PP1 = "off" | "bn,S"
     int pp_dbg = -1;                        // MAA_PP_DBG: ablation mask of igemm_pp's TUNE instantiation (-1: product kernel)
     bool op_presplit = false;               // MAA_OP_PRESPLIT=1: the maa_op_* test entry points hand activations over as split32
+    int dma_ns_low = 0;                     // MAA_DMA_NS_LOW: LDS stages of a 64x64 LDS-DMA launch with < 2.5 workgroups per CU (0: as the others)
+    bool rowchain = true;                   // MAA_ROWCHAIN=0: the transformer's short-K linears stay separate launches (A/B, tests)
     void load();
 };
 
@@ -237,6 +239,7 @@ void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, con
 // fp32 [rows, C] -> split32 rows of the same pitch (C % 32 == 0): tests and micro-benchmarks of the engines that take
 // pre-split activations (in the models the normalisations write this form directly)
 void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, float* out, float slope = 1.f);
+void launch_split32_unpack(const Ctx& ctx, const float* x, long long rows, int C, float* out);      // hi + lo back to fp32 (tests)
 // fused softmax(alpha q k^T) v for the bf16 precision modes; false = shape not covered, use the GEMM path
 bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
                             const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,
@@ -276,6 +279,9 @@ void launch_leaky(const Ctx& ctx, const float* x, long long n, float slope, floa
 void launch_clamp_affine(const Ctx& ctx, const float* x, long long n, float mul, float add, float lo, float hi,
                          float* out);
 
+// box calibration (calib.hip): kind 0 -> dense bf16 MFMA TFLOP/s of a fixed register-only loop, kind 1 -> GB/s of a 256 MiB copy
+double calib_run(const Ctx& ctx, int kind);
+
 // ------------------------------------------------------------------------------------------ weights
 struct HostTensor {
     const float* data = nullptr;
@@ -298,6 +304,31 @@ struct PackedW {
     int ld = 0, nk = 0;
     int split = 0;          // 1: rows of w are split32 lines (row pitch ld floats)
 };
+
+// Row-chain engine (rowchain.hip): per 64-row block  y = a.W1^T + b1 (+res1);  t = LayerNorm(y) or y;  z = t.W2^T + b2 (+res2),
+// with the intermediate rows kept on the CU.  N = w1.N must be the whole row (320 or 256); w2.N a multiple of it.
+struct RowChain {
+    int M = 0;
+    const float* a = nullptr;        // split32 rows [M, w1.K], pitch lda floats
+    int lda = 0;
+    PackedW w1;
+    const float* res1 = nullptr;     // fp32 [M, N], pitch ldr1
+    int ldr1 = 0;
+    float* y = nullptr;              // optional fp32 copy of the stage-1 rows (the residual of a later layer)
+    int ldy = 0;
+    const float* ln_g = nullptr;     // LayerNorm between the stages (null: none)
+    const float* ln_b = nullptr;
+    float eps = 1e-5f;
+    float* t_out = nullptr;          // optional split32 copy of the (normalised) rows, pitch ldt
+    int ldt = 0;
+    const PackedW* w2 = nullptr;     // stage 2 (null: none)
+    const float* res2 = nullptr;     // fp32 [M, N] (only when w2->N == N)
+    int ldr2 = 0;
+    float* z = nullptr;              // [M, w2->N] fp32, or split32 rows when z_split
+    int ldz = 0, z_split = 0;
+};
+bool rowchain_covers(const Ctx& ctx, const RowChain& d);
+void launch_rowchain(const Ctx& ctx, const RowChain& d);
 
 // Conv1d(C, C, k, dilation) with "same" padding for the narrow vocoder stages (C = 32 / 64), bf16x3: the input tile is
 // staged once in LDS and every tap reads it at a row offset (halo_conv1d.hip).  false: not covered, use the implicit GEMM.

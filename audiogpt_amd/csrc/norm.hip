@@ -273,7 +273,27 @@ __global__ __launch_bounds__(256) void split32_pack_kernel(const float* __restri
     }
 }
 
+// split32 rows -> fp32 rows (hi + lo): tests of the kernels that only emit the split form
+__global__ __launch_bounds__(256) void split32_unpack_kernel(const float* __restrict__ x, long long rows, int C, float* __restrict__ out) {
+    const long long n = rows * C;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long row = i / C;
+        const int c = (int)(i - row * C);
+        const unsigned short* line = reinterpret_cast<const unsigned short*>(x) + row * C * 2 + (c >> 5) * 64 + (c & 31);
+        out[i] = __builtin_bit_cast(float, (unsigned)line[0] << 16) + __builtin_bit_cast(float, (unsigned)line[32] << 16);
+    }
+}
+
 }  // namespace
+
+void launch_split32_unpack(const Ctx& ctx, const float* x, long long rows, int C, float* out) {
+    if (ctx.ws.dry) return;
+    MAA_CHECK(C % 32 == 0, "split32 rows are whole 32-channel lines");
+    const long long n = rows * C;
+    const unsigned grid = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(split32_unpack_kernel, dim3(grid), dim3(256), 0, ctx.stream, x, rows, C, out);
+    MAA_HIP(hipGetLastError());
+}
 
 void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, float* out, float slope) {
     if (ctx.ws.dry) return;

@@ -170,6 +170,10 @@ void Tuning::load() {
     pp_dbg = pd.empty() ? -1 : std::atoi(pd.c_str());
     const std::string ps = get_s("MAA_OP_PRESPLIT");
     op_presplit = !ps.empty() && ps[0] == '1';
+    const std::string nl = get_s("MAA_DMA_NS_LOW");
+    dma_ns_low = nl.empty() ? 0 : std::atoi(nl.c_str());
+    const std::string rc = get_s("MAA_ROWCHAIN");
+    rowchain = rc.empty() || rc[0] != '0';
 }
 
 void StepGraph::clear() {

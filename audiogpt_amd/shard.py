@@ -6,8 +6,9 @@ per-sample), so prompts shard as contiguous blocks with full weight replicas and
 loop:
   C0  x_T: every rank regenerates RandomState(seed).randn(n_total, ...) and slices its block -- bit-identical
       to the single-GPU run, nothing is sent
-  C1  conditioning: the rank that ran the text/image encoder broadcasts c [n_total, L, 1024] (and the single
-      unconditional row) over xGMI; each rank keeps its slice
+  C1  conditioning: the rank that ran the text/image encoder SCATTERS c [n_total, L, 1024] -- every peer receives only its
+      own block (2.5 MB of a 64-prompt job's 20 MB) -- and broadcasts the single unconditional row over xGMI
+      (`mode="broadcast"` keeps the round-1 form: everything to everyone, each rank slices)
   C2  waveforms: gathered to rank 0
 Works with any backend ("gloo" on CPU in the tests).
 """
@@ -29,11 +30,13 @@ def start_codes(seed, n_total, shape, world=1, rank=0):
     return torch.from_numpy(x[lo:hi]).to(torch.float32)
 
 
-def broadcast_conditioning(c_all, uc_row, n_local, device, dist=None, src=0, shape=None):
+def broadcast_conditioning(c_all, uc_row, n_local, device, dist=None, src=0, shape=None, mode="scatter"):
     """C1.  c_all [n_total, L, D] and uc_row [1, L, D] exist on `src` (None elsewhere).
     Returns (c_local [n_local, L, D], uc_local [n_local, L, D]) on every rank.
     `shape` = (n_total, L, D) when every rank already knows it (a serving loop with fixed batch geometry): skips the
-    metadata broadcast and its device -> host synchronisation."""
+    metadata broadcast and its device -> host synchronisation.
+    mode "scatter" (default): `src` sends rank r its own block only (one grouped send/recv on RCCL; blocks of ragged jobs
+    are padded to the largest); "broadcast": the whole tensor to every rank, sliced locally."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return c_all[:n_local].contiguous(), uc_row.expand(n_local, -1, -1).contiguous()
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -45,14 +48,63 @@ def broadcast_conditioning(c_all, uc_row, n_local, device, dist=None, src=0, sha
             meta = torch.tensor([c_all.shape[0], c_all.shape[1], c_all.shape[2]], dtype=torch.int64, device=device)
         dist.broadcast(meta, src)
         n_total, L, D = (int(v) for v in meta.tolist())
-    if rank != src:
-        c_all = torch.empty(n_total, L, D, dtype=torch.float32, device=device)
-        uc_row = torch.empty(1, L, D, dtype=torch.float32, device=device)
-    dist.broadcast(c_all, src)
-    dist.broadcast(uc_row, src)
     lo, hi = shard_range(n_total, world, rank)
     assert hi - lo == n_local, (lo, hi, n_local)
-    return c_all[lo:hi].contiguous(), uc_row.expand(n_local, -1, -1).contiguous()
+    if rank != src:
+        uc_row = torch.empty(1, L, D, dtype=torch.float32, device=device)
+    if mode == "broadcast":
+        if rank != src:
+            c_all = torch.empty(n_total, L, D, dtype=torch.float32, device=device)
+        dist.broadcast(c_all, src)
+        c_local = c_all[lo:hi].contiguous()
+    else:
+        spans = [shard_range(n_total, world, r) for r in range(world)]
+        nmax = max(b - a for a, b in spans)
+        recv = torch.empty(nmax, L, D, dtype=torch.float32, device=device)
+        blocks = None
+        if rank == src:
+            blocks = []
+            for a, b in spans:
+                if b - a == nmax:
+                    blocks.append(c_all[a:b].contiguous())
+                else:       # ragged job: pad the short blocks (scatter moves equal-sized pieces)
+                    pad = torch.zeros(nmax, L, D, dtype=torch.float32, device=device)
+                    pad[: b - a] = c_all[a:b]
+                    blocks.append(pad)
+        dist.scatter(recv, blocks, src=src)
+        c_local = recv[:n_local].contiguous()
+    dist.broadcast(uc_row, src)
+    return c_local, uc_row.expand(n_local, -1, -1).contiguous()
+
+
+def ranks_seen(device, dist=None):
+    """Identity of the device every rank runs on, gathered to all ranks: the first N > 1 run can check that RCCL really had N
+    distinct GPUs (a mis-set HIP_VISIBLE_DEVICES puts every rank on one).  Returns {"ids": [...], "n_distinct": k}."""
+    mine = device_identity(device)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return {"ids": [mine], "n_distinct": 1}
+    ids = [None] * dist.get_world_size()
+    dist.all_gather_object(ids, mine)
+    return {"ids": ids, "n_distinct": len(set(ids))}
+
+
+def device_identity(device):
+    """'pci:dddd:bb:dd.f' (or the device UUID) of a CUDA/HIP device; 'cpu:<pid>' for the CPU stand-in of the tests."""
+    import os
+    device = torch.device(device)
+    if device.type != "cuda":
+        return "cpu:%d" % os.getpid()
+    try:
+        pr = torch.cuda.get_device_properties(device)
+        bus, dv = getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None)
+        if bus is not None and dv is not None:
+            return "pci:%04x:%02x:%02x.0" % (int(getattr(pr, "pci_domain_id", 0) or 0), int(bus), int(dv))
+        uuid = getattr(pr, "uuid", None)
+        if uuid is not None:
+            return "uuid:%s" % uuid
+    except Exception:
+        pass
+    return "cuda-index:%d" % (device.index if device.index is not None else torch.cuda.current_device())
 
 
 def gather_waveforms(wav_local, dist=None, dst=0, counts=None):

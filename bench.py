@@ -182,18 +182,60 @@ class BoxSampler:
     several percent and follows the clock a box sustains under this load; nothing here is required --
     every failure yields None."""
 
-    def __init__(self, root="/sys/class/drm", period=0.5):
+    def __init__(self, device=None, root="/sys/class/drm", period=0.5, pci_root="/sys/bus/pci/devices"):
+        """device: the torch device the benchmark runs on.  Its PCI address (domain:bus:device.function of the HIP device, from
+        torch.cuda.get_device_properties / hipDeviceGetPCIBusId) selects the sysfs node; only when that cannot be resolved does
+        the sampler fall back to the first amdgpu card it finds, and says so in `matched_by`."""
         import glob
         import threading
         self.sclk, self.power, self.period = [], [], period
         self._stop = threading.Event()
         self._thread = None
         self.card = None
-        for c in sorted(glob.glob(os.path.join(root, "card[0-9]*"))):
-            if os.path.exists(os.path.join(c, "device", "pp_dpm_sclk")):
-                self.card = os.path.join(c, "device")
-                break
+        self.bdf = self.pci_bdf(device)
+        self.matched_by = None
+        if self.bdf:
+            cand = os.path.join(pci_root, self.bdf)
+            if os.path.exists(os.path.join(cand, "pp_dpm_sclk")):
+                self.card, self.matched_by = cand, "pci_bus_id"
+            else:       # the same device through its DRM node (containers that hide /sys/bus/pci)
+                for c in sorted(glob.glob(os.path.join(root, "card[0-9]*"))):
+                    try:
+                        if os.path.basename(os.path.realpath(os.path.join(c, "device"))) == self.bdf and \
+                                os.path.exists(os.path.join(c, "device", "pp_dpm_sclk")):
+                            self.card, self.matched_by = os.path.join(c, "device"), "drm_node_of_pci_bus_id"
+                            break
+                    except OSError:
+                        continue
+        if self.card is None:
+            for c in sorted(glob.glob(os.path.join(root, "card[0-9]*"))):
+                if os.path.exists(os.path.join(c, "device", "pp_dpm_sclk")):
+                    self.card, self.matched_by = os.path.join(c, "device"), "first_amdgpu_card (PCI address of the HIP device not resolved)"
+                    break
         self._hw = sorted(glob.glob(os.path.join(self.card, "hwmon", "hwmon*"))) if self.card else []
+
+    @staticmethod
+    def pci_bdf(device):
+        """'dddd:bb:dd.f' of a torch CUDA(HIP) device, or None."""
+        if device is None:
+            return None
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            dom, bus, dv = (getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+            if bus is not None and dv is not None:
+                return "%04x:%02x:%02x.0" % (int(dom or 0), int(bus), int(dv))
+        except Exception:
+            pass
+        try:      # older torch: ask the HIP runtime
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(idx)) == 0:
+                return buf.value.decode().lower()
+        except Exception:
+            pass
+        return None
 
     @staticmethod
     def parse_sclk(text):
@@ -241,7 +283,8 @@ class BoxSampler:
         def med(v):
             return sorted(v)[len(v) // 2] if v else None
         return {"sclk_mhz_median": med(self.sclk), "sclk_mhz_min": min(self.sclk) if self.sclk else None,
-                "socket_power_w_median": med(self.power), "samples": len(self.sclk),
+                "socket_power_w_median": med(self.power), "socket_power_w_max": max(self.power) if self.power else None,
+                "samples": len(self.sclk), "pci_bus_id": self.bdf, "matched_by": self.matched_by,
                 "source": "amdgpu sysfs (pp_dpm_sclk, hwmon power) of %s, sampled during the timed region" % self.card}
 
 
@@ -518,7 +561,7 @@ def main(argv=None):
     from concurrent.futures import ThreadPoolExecutor
 
     from audiogpt_amd.pipeline import MakeAnAudio
-    from audiogpt_amd.shard import broadcast_conditioning, gather_waveforms, run_in_flight, start_codes
+    from audiogpt_amd.shard import broadcast_conditioning, gather_waveforms, ranks_seen, run_in_flight, start_codes
     # One batch of 8 prompts leaves much of the chip idle (its kernels are short and latency-bound: two independent
     # batches side by side finish in 1.57x the time of one, profiles/r2_dual_stream_probe.txt), so consecutive steps of the
     # benchmark -- independent prompt batches, each sampled exactly as BASELINE configs[1] says -- are kept `inflight` at
@@ -617,7 +660,17 @@ def main(argv=None):
     barrier()
     for v in comm_events.values():
         v.clear()
-    sampler = BoxSampler() if (rank == 0 and not stub) else None
+    # box calibration right before the timed region (rank 0): what a fixed MFMA loop and a fixed copy reach on this box now
+    calib = None
+    if rank == 0 and not stub:
+        try:
+            calib = pipe.ctx.calib()
+            calib["note"] = ("csrc/calib.hip on the first replica's stream: dense bf16 MFMA loop (peak 2500 TFLOP/s at 2.4 GHz) "
+                             "and a 256 MiB float4 copy (read + written bytes)")
+        except Exception as e:      # never lose the line to the calibration
+            calib = {"error": str(e)[:200]}
+        barrier()
+    sampler = BoxSampler(dev) if (rank == 0 and not stub) else None
     if sampler is not None:
         sampler.__enter__()
     t0 = time.perf_counter()
@@ -626,10 +679,16 @@ def main(argv=None):
     elapsed = time.perf_counter() - t0
     if sampler is not None:
         sampler.__exit__()
+    per_rank_elapsed = [elapsed]
     if dist is not None:
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_elapsed = [float(e.item()) for e in every]
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    seen = ranks_seen(dev, dist) if world > 1 else None
 
     # device time of the two collectives of a step (events on the main thread's stream, this rank): their share of a step is
     # what the first multi-GPU run should look at before anything else
@@ -655,6 +714,13 @@ def main(argv=None):
     }
     if sampler is not None:
         result["box"] = sampler.summary()
+        if calib is not None:
+            result["box"]["calib"] = calib
+    if world > 1:
+        # proof of what an N > 1 line ran on: the device identity of every rank (PCI address; must be N distinct ones) and each
+        # rank's own rate over its own clock (the line's value uses the slowest rank's time)
+        result["ranks_seen"] = seen
+        result["per_rank_value"] = [pipe.audio_seconds(n, CLIP_FRAMES) * args.steps / e for e in per_rank_elapsed]
 
     if rank == 0 and not args.no_roofline:
         # one more batch, eager (graph launches cannot be event-timed), every kernel bracketed by hipEvents on the

@@ -322,6 +322,11 @@ int maa_resampler_create(maa_ctx* ctx, int orig, int neu, int width, int klen, c
 int maa_resampler_destroy(maa_resampler* r);
 int maa_resampler_forward(maa_ctx* ctx, maa_resampler* r, const float* d_wav, int B, int n, float* d_out);
 
+/* Box calibration for the benchmark's `box.calib` record (no counterpart in the reference): kind 0 = a fixed register-only
+ * loop of dense bf16 MFMAs -> TFLOP/s the box sustains, kind 1 = a fixed 256 MiB device copy -> GB/s (read + written).  Timed
+ * with HIP events on the context's stream. */
+int maa_calib(maa_ctx* ctx, int kind, double* out_value);
+
 /* ---- single-operator entry points (parity tests and profiling of individual kernels) ------------ */
 /* y[M,N] = A[M,K] * W^T (+bias) with W given as torch Linear weight [N,K] on the HOST; A, y on device */
 int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w, const float* h_bias, int N,
@@ -330,6 +335,13 @@ int maa_op_linear(maa_ctx* ctx, const float* d_a, int M, int K, const float* h_w
 int maa_op_conv(maa_ctx* ctx, const float* d_x, int B, int Cin, int H, int W, const float* h_w, const float* h_bias,
                 int Cout, int KH, int KW, int stride, int pad, int dil, int upsample2, float leaky_slope,
                 float* d_y, int Ho, int Wo);
+/* the row-chain engine (csrc/rowchain.hip) on its own: y = a W1^T + b1 (+res1); t = LayerNorm(y) if h_ln_g else y;
+ * z = t W2^T + b2 (+res2) -- the fused form of attention.py:196-215, 250-261's linear -> LayerNorm -> linear chains.
+ * d_a [M,K1], d_res1 / d_y / d_t [M,N] (N = 320 or 256), d_res2 (only when N2 == N), d_z [M,N2]: fp32 on the device;
+ * torch Linear weights h_w1 [N,K1], h_w2 [N2,N] on the HOST; any of d_res1, d_y, h_ln_g/b, d_t, h_w2.., d_res2 may be null */
+int maa_op_rowchain(maa_ctx* ctx, const float* d_a, int M, int K1, int N, const float* h_w1, const float* h_b1,
+                    const float* d_res1, float* d_y, const float* h_ln_g, const float* h_ln_b, float eps, float* d_t,
+                    const float* h_w2, const float* h_b2, int N2, const float* d_res2, float* d_z);
 /* GroupNorm(32 groups)(+SiLU) on d_x [B,C,HW] */
 int maa_op_groupnorm(maa_ctx* ctx, const float* d_x, int B, int C, int HW, const float* h_gamma,
                      const float* h_beta, float eps, int silu, float* d_y);

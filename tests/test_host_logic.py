@@ -204,6 +204,35 @@ def test_bench_box_sampler_reads_amdgpu_sysfs(tmp_path):
     with bench.BoxSampler(root=str(tmp_path / "nothing")) as sm:
         pass
     assert sm.summary()["sclk_mhz_median"] is None and sm.summary()["samples"] == 0
+    assert r["matched_by"].startswith("first_amdgpu_card") and r["pci_bus_id"] is None
+
+
+def test_bench_box_sampler_follows_the_hip_devices_pci_address(tmp_path, monkeypatch):
+    """On a multi-GPU host the sampled card must be the HIP device's own: a fake PCI tree with two cards, the second one ours
+    (the first card with pp_dpm_sclk was sampled whatever device the benchmark ran on)."""
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    pci = tmp_path / "pci"
+    for bdf, mhz, uw in (("0000:05:00.0", 132, 90000000), ("0000:85:00.0", 2210, 1380000000)):
+        d = pci / bdf
+        (d / "hwmon" / "hwmon7").mkdir(parents=True)
+        (d / "pp_dpm_sclk").write_text("0: 132Mhz%s\n1: %dMhz%s\n" % (" *" if mhz == 132 else "", max(mhz, 133), " *" if mhz != 132 else ""))
+        (d / "hwmon" / "hwmon7" / "power1_average").write_text("%d\n" % uw)
+    monkeypatch.setattr(bench.BoxSampler, "pci_bdf", staticmethod(lambda device: "0000:85:00.0"))
+    with bench.BoxSampler(device="cuda:1", root=str(tmp_path / "nodrm"), pci_root=str(pci), period=0.02) as sm:
+        time.sleep(0.15)
+    r = sm.summary()
+    assert r["pci_bus_id"] == "0000:85:00.0" and r["matched_by"] == "pci_bus_id"
+    assert r["sclk_mhz_median"] == 2210 and abs(r["socket_power_w_median"] - 1380.0) < 1e-6
+    # the address as torch reports it: three integers -> dddd:bb:dd.f
+    class P:
+        pci_domain_id, pci_bus_id, pci_device_id = 0, 0x85, 0
+    monkeypatch.undo()
+    import torch
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda d: P())
+    assert bench.BoxSampler.pci_bdf("cuda:1") == "0000:85:00.0"
 
 
 def test_mel_front_end_restatement():

@@ -16,7 +16,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "audiogpt_amd", "csrc")
-FILES = ["igemm_pp.hip", "igemm_dma.hip", "igemm_dma2.hip", "igemm_bf16.hip", "igemm_f32.hip", "flash_attn.hip", "halo_conv1d.hip"]
+FILES = ["igemm_pp.hip", "rowchain.hip", "igemm_dma.hip", "igemm_dma2.hip", "igemm_bf16.hip", "igemm_f32.hip", "flash_attn.hip", "halo_conv1d.hip"]
 
 
 def _hipcc():
@@ -83,13 +83,18 @@ def mfma_loops_without_scratch(body):
     return len(inner), len(bad)
 
 
+def _pp_tune_build(name):
+    """igemm_pp_kernel<MI, NI, GWM, GWN, NPA, TUNE, PERSIST, OUT>: TUNE is the first bool of the mangled argument list."""
+    return "igemm_pp_kernel" in name and re.search(r"Li[13]ELb1ELb[01]ELi\dEEEv", name) is not None
+
+
 def test_no_scratch_inside_any_mfma_loop(asm):
     seen = 0
     for f, text in asm.items():
         for name, body in kernels(text).items():
             if not any("v_mfma" in l for l in body):
                 continue
-            if f == "igemm_pp.hip" and "Lb1EEEv" in name:
+            if f == "igemm_pp.hip" and _pp_tune_build(name):
                 continue      # TUNE = true: the ablation build (MAA_PP_DBG), timing only, never selected by default
             if f == "igemm_f32.hip" and "ILi128ELi128ELi2ELi2ELb0E" in name:
                 # KNOWN, exact-fp32 mode only: the unaligned-operand path of the 128x128 tile indexes its staging registers
@@ -106,7 +111,7 @@ def test_no_scratch_inside_any_mfma_loop(asm):
 def test_engines_use_the_instructions_the_design_names(asm):
     def count(f, pat):
         return len(re.findall(pat, asm[f]))
-    for f in ("igemm_pp.hip", "igemm_dma.hip", "igemm_dma2.hip", "halo_conv1d.hip"):
+    for f in ("igemm_pp.hip", "rowchain.hip", "igemm_dma.hip", "igemm_dma2.hip", "halo_conv1d.hip"):
         assert count(f, r"global_load_lds_dwordx4|global_load_lds") > 0, f
         assert count(f, r"v_mfma_f32_32x32x16_bf16") > 0, f
     assert count("igemm_bf16.hip", r"v_mfma_f32_32x32x16_bf16") > 0 and count("igemm_bf16.hip", r"global_load_lds") == 0
@@ -127,8 +132,15 @@ def test_register_budgets(asm):
     for (f, name), (vg, spill) in meta.items():
         if f == "igemm_pp.hip":
             assert vg <= 256, (name, vg)
-            if "Li1ELi5E" not in name and "Lb1EEEv" not in name:      # not the 160-wide tile, not the tuning build
-                assert spill == 0, (name, spill)
+            if _pp_tune_build(name):
+                continue
+            # the 160-wide tile spills only where its result leaves through the fused epilogue (the vocoders' 1-D layers never
+            # take it: they are 128 wide); the slab-only instantiations -- every 3x3 convolution of the UNet -- have no scratch
+            if "igemm_pp_kernel" in name and "ILi1ELi5E" in name and re.search(r"ELi1EEEv", name):
+                continue
+            if "igemm_pp1_kernel" in name and "ILi1ELi5E" in name:      # (the 1x1 form's 160-wide tile: forced by MAA_PP1 only)
+                continue
+            assert spill == 0, (name, spill)
         elif f == "flash_attn.hip":
             assert spill == 0, (name, spill)
             if "ILi40ELi3E" in name:          # the 780-token self-attention: 896 workgroups want three per CU

@@ -19,7 +19,7 @@ from audiogpt_amd import shard  # noqa: E402
 
 def _fake_generate(x_T, c, uc):
     """Per-sample, batch-independent stand-in for DDIM+VAE+vocoder: wav[i] depends only on sample i."""
-    feat = (c.mean(dim=(1, 2)) - uc.mean(dim=(1, 2)))[:, None] + x_T.reshape(x_T.shape[0], -1).sum(dim=1, keepdim=True)
+    feat = (c.mean(dim=(1, 2)) - uc.mean(dim=(1, 2)))[:, None] + x_T.flatten(1).sum(dim=1, keepdim=True)      # (rows may be 0: a rank without prompts)
     t = torch.arange(64, dtype=torch.float32)[None, :]
     return torch.sin(feat * 0.01 + t * 0.1)
 
@@ -32,7 +32,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, out_path, known=False):
+def _worker(rank, world, port, n_total, out_path, known=False, mode="scatter"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -48,10 +48,13 @@ def _worker(rank, world, port, n_total, out_path, known=False):
     # known = the batch geometry is agreed up front (bench.py's timed loop): no metadata / count exchange
     shape = (n_total, 7, 16) if known else None
     counts = [b - a for a, b in (shard.shard_range(n_total, world, r) for r in range(world))] if known else None
-    c, uc = shard.broadcast_conditioning(c_all, uc_row, hi - lo, dev, dist, shape=shape)
+    c, uc = shard.broadcast_conditioning(c_all, uc_row, hi - lo, dev, dist, shape=shape, mode=mode)
+    assert c.shape[0] == hi - lo
     x_T = shard.start_codes(55, n_total, (4, 2, 3), world, rank)
     wav = _fake_generate(x_T, c, uc)
     full = shard.gather_waveforms(wav, dist, counts=counts)
+    seen = shard.ranks_seen(dev, dist)
+    assert len(seen["ids"]) == world and seen["n_distinct"] == world, seen      # one process (here: pid) per rank
     if rank == 0:
         np.save(out_path, full.numpy())
     else:
@@ -60,10 +63,14 @@ def _worker(rank, world, port, n_total, out_path, known=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total,known", [(8, False), (5, False), (8, True), (5, True)])
-def test_sharded_equals_single_process(tmp_path, n_total, known):
+@pytest.mark.parametrize("world,n_total,known,mode", [(2, 8, False, "scatter"), (2, 5, False, "scatter"), (2, 8, True, "scatter"),
+                                                      (2, 5, True, "broadcast"), (3, 8, True, "scatter"), (3, 7, False, "broadcast"),
+                                                      (8, 64, True, "scatter"), (8, 13, False, "scatter"), (8, 5, True, "scatter")])
+def test_sharded_equals_single_process(tmp_path, world, n_total, known, mode):
+    """C0 / C1 / C2 with 2, 3 and 8 ranks (BASELINE configs[3] is 8-way), even, ragged and fewer-prompts-than-ranks jobs, C1 as
+    the per-peer scatter and as the round-1 broadcast."""
     out = str(tmp_path / "wav.npy")
-    mp.spawn(_worker, args=(2, _free_port(), n_total, out, known), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_total, out, known, mode), nprocs=world, join=True)
     got = np.load(out)
     g = torch.Generator().manual_seed(1234)
     c_all = torch.randn(n_total, 7, 16, generator=g)
@@ -173,6 +180,10 @@ def test_bench_main_multi_rank_control_flow(tmp_path, inflight):
     world, out = 2, str(tmp_path / "line.json")
     mp.spawn(_bench_worker, args=(world, _free_port(), out, inflight), nprocs=world, join=True)
     d = json.load(open(out))
+    # the N > 1 line proves what it ran on: one identity per rank, all distinct, and every rank's own rate
+    assert len(d["ranks_seen"]["ids"]) == 2 and d["ranks_seen"]["n_distinct"] == 2
+    assert len(d["per_rank_value"]) == 2 and all(v > 0 for v in d["per_rank_value"])
+    assert d["value"] <= sum(d["per_rank_value"]) * (1 + 1e-9)      # max-over-ranks time: the whole job is no faster than its parts
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"]
     assert d["config"]["batches_in_flight"] == inflight and d["config"]["prompts_per_gpu"] == 8
     assert ("in flight" in d["metric"]) == (inflight > 1)
