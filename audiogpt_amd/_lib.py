@@ -42,7 +42,11 @@ class maa_ddim_args(C.Structure):
                 ("d_cond", C.c_void_p), ("d_uncond", C.c_void_p), ("L", C.c_int),
                 ("d_concat", C.c_void_p), ("Cc", C.c_int),
                 ("h_timesteps", C.POINTER(C.c_int32)), ("h_alphas", C.POINTER(C.c_float)),
-                ("h_alphas_prev", C.POINTER(C.c_float)), ("use_graph", C.c_int)]
+                ("h_alphas_prev", C.POINTER(C.c_float)), ("use_graph", C.c_int),
+                ("d_mask", C.c_void_p), ("d_x0", C.c_void_p), ("d_noise_q", C.c_void_p),
+                ("h_sqrt_ac", C.POINTER(C.c_float)), ("h_sqrt_1mac", C.POINTER(C.c_float)),
+                ("h_sigmas", C.POINTER(C.c_float)), ("d_noise_p", C.c_void_p), ("temperature", C.c_float),
+                ("log_every_t", C.c_int), ("n_log", C.c_int), ("d_log_x", C.c_void_p), ("d_log_x0", C.c_void_p)]
 
 
 class maa_vae_config(C.Structure):

@@ -282,8 +282,13 @@ class UNet:
     __call__ = forward
 
     def ddim_sample(self, x_T, timesteps, alphas, alphas_prev, cond=None, uncond=None, scale=1.0, concat=None,
-                    use_graph=True):
-        """Whole DDIM trajectory on the device (ddim.py:118-225, eta = 0).  Returns x_0."""
+                    use_graph=True, mask=None, x0=None, noise_q=None, sqrt_ac=None, sqrt_1mac=None, sigmas=None,
+                    noise_p=None, temperature=1.0, log_every_t=None):
+        """Whole DDIM trajectory on the device (ddim.py:118-225).  Returns x_0, or (x_0, x_inter, pred_x0) when
+        log_every_t is given (the two logs as [n_log, B, C, H, W] tensors, ddim.py:158-163).
+        mask / x0 / noise_q [S, B, C, H, W] / sqrt_ac, sqrt_1mac [S]: the mask blend of ddim.py:147-150;
+        sigmas [S] / noise_p [S, B, C, H, W] / temperature: the eta > 0 noise term of ddim.py:210-225.  Noise tensors
+        are in loop order (first step first)."""
         dev = self.ctx.device
         x = _f32(x_T, dev).clone()
         B, Cc, H, W = x.shape
@@ -326,8 +331,47 @@ class UNet:
         a.h_alphas = al.ctypes.data_as(C.POINTER(C.c_float))
         a.h_alphas_prev = ap.ctypes.data_as(C.POINTER(C.c_float))
         a.use_graph = int(use_graph)
+        S = len(ts)
+
+        def host_table(v, what):
+            t = np.ascontiguousarray(np.asarray(v), dtype=np.float32)
+            if t.shape != (S,):
+                raise L.MaaError("ddim_sample: %s must hold one value per DDIM step (%d), got %s" % (what, S, t.shape))
+            keep.append(t)
+            return t.ctypes.data_as(C.POINTER(C.c_float))
+
+        def step_noise(v, what):
+            t = _f32(v, dev)
+            if tuple(t.shape) != (S, B, Cc, H, W):
+                raise L.MaaError("ddim_sample: %s must be [S=%d, %d, %d, %d, %d], got %s" % (what, S, B, Cc, H, W, tuple(t.shape)))
+            keep.append(t)
+            return t.data_ptr()
+
+        if mask is not None:
+            if x0 is None or noise_q is None or sqrt_ac is None or sqrt_1mac is None:
+                raise L.MaaError("ddim_sample: mask needs x0, noise_q and the q_sample tables")      # ddim.py:148 asserts x0
+            m = _f32(mask, dev).expand(B, Cc, H, W).contiguous()
+            z0 = _f32(x0, dev).expand(B, Cc, H, W).contiguous()
+            keep += [m, z0]
+            a.d_mask, a.d_x0 = m.data_ptr(), z0.data_ptr()
+            a.d_noise_q = step_noise(noise_q, "noise_q")
+            a.h_sqrt_ac, a.h_sqrt_1mac = host_table(sqrt_ac, "sqrt_ac"), host_table(sqrt_1mac, "sqrt_1mac")
+        if sigmas is not None:
+            if noise_p is None:
+                raise L.MaaError("ddim_sample: sigmas (eta > 0) need noise_p")
+            a.h_sigmas = host_table(sigmas, "sigmas")
+            a.d_noise_p = step_noise(noise_p, "noise_p")
+        a.temperature = float(temperature)
+        logs = None
+        if log_every_t is not None:
+            n_log = sum(1 for i in range(S) if i % int(log_every_t) == 0 or i == S - 1)
+            logs = (torch.empty(n_log, B, Cc, H, W, device=dev), torch.empty(n_log, B, Cc, H, W, device=dev))
+            a.log_every_t, a.n_log = int(log_every_t), n_log
+            a.d_log_x, a.d_log_x0 = logs[0].data_ptr(), logs[1].data_ptr()
         with self.ctx.lock:
             L.check(self.ctx.lib.maa_ddim_sample(self.ctx.h, self.h, C.byref(a), L.dptr(x)))
+        if logs is not None:
+            return x, logs[0], logs[1]
         return x
 
     def close(self):

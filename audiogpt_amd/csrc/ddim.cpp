@@ -1,7 +1,9 @@
 // Device-resident DDIM loop: S x { build UNet input, UNet forward (2B with CFG), CFG combine + x_{t-1} update }.
 //
 // Mirrors ldm/models/diffusion/ddim.py:118-166 (ddim_sampling) and :169-225 (p_sample_ddim) of the
-// reference for the tools' call pattern (eta = 0, no mask / score corrector / quantisation):
+// reference: the tools' call pattern (eta = 0, no mask) and, since round 4, the rest of sample()'s signature that is pure
+// tensor arithmetic -- mask / x0 blending (:147-150), eta > 0 with the caller's noise (:210-225), the logged intermediates
+// (:158-163); score correctors, quantisation, dropout noise and host callbacks stay out:
 //   CFG batch order is [uncond ; cond] on x, t and context (:177-199)
 //   concat conditioning is cat([x, c], dim=1) (ldm/models/diffusion/ddpm.py:1404-1406)
 // Nothing returns to the host inside the loop: per-step scalars (t, a_t, a_prev, sqrt(1-a_t)) are rows of
@@ -31,15 +33,28 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
 
     // ---- device state of the loop, in one slab the context keeps across calls: tables (one row per DDIM index), the
     // device step index, the step's timestep / coefficient slots, UNet input and output
-    std::vector<float> h_tab((size_t)a.S * 5);
-    for (int i = 0; i < a.S; ++i) {
+    const bool masked = a.d_mask != nullptr;
+    MAA_CHECK(!masked || (a.d_x0 && a.d_noise_q && a.h_sqrt_ac && a.h_sqrt_1mac), "ddim: mask needs x0, its noise and the q_sample tables");
+    MAA_CHECK(!a.h_sigmas || a.d_noise_p, "ddim: eta > 0 needs the steps' noise");
+    const bool logging = a.n_log > 0;
+    MAA_CHECK(!logging || (a.d_log_x && a.d_log_x0 && a.log_every_t > 0), "ddim: intermediates need their buffers and log_every_t");
+    std::vector<float> h_tab((size_t)a.S * 9);
+    int n_logged = 0;
+    for (int v = 0; v < a.S; ++v) {                    // visiting order: index S-1 first (ddim.py:143-145)
+        const int i = a.S - 1 - v;
         h_tab[i] = (float)a.h_timesteps[i];
-        float* cf = &h_tab[(size_t)a.S + (size_t)i * 4];
+        float* cf = &h_tab[(size_t)a.S + (size_t)i * 8];
         cf[0] = a.h_alphas[i];
         cf[1] = a.h_alphas_prev[i];
-        cf[2] = 0.f;                                   // eta = 0
+        cf[2] = a.h_sigmas ? a.h_sigmas[i] : 0.f;      // eta = 0: no noise term
         cf[3] = std::sqrt(1.0f - a.h_alphas[i]);       // ddim.py:52 (fp32 sqrt of fp32 1-a)
+        cf[4] = masked ? a.h_sqrt_ac[i] : 0.f;
+        cf[5] = masked ? a.h_sqrt_1mac[i] : 0.f;
+        const bool logged = logging && (i % a.log_every_t == 0 || i == a.S - 1);      // ddim.py:161
+        cf[6] = logged ? (float)n_logged++ : -1.f;
+        cf[7] = (float)i;
     }
+    MAA_CHECK(!logging || n_logged == a.n_log, "ddim: n_log does not match log_every_t");
     auto up = [](size_t n) { return (n + 63) / 64 * 64; };      // floats, 256-byte aligned pieces
     const size_t n_cc = concat ? (size_t)a.B * (per_in - per) : 0;
     const size_t o_tab = 0, o_step = o_tab + up(h_tab.size()), o_t = o_step + 64, o_coef = o_t + up(nB),
@@ -67,10 +82,11 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
     // one step: identical launches on identical addresses whatever the step (the index lives on the device)
     auto step_body = [&]() {
         launch_ddim_prepare(ctx, xs, concat ? ccs : nullptr, a.B, nB, per, per_in - per, tab_t, tab_coef, d_step, xin,
-                            cur_t, cur_coef);
+                            cur_t, cur_coef, a.d_mask, a.d_x0, a.d_noise_q, a.S);
         unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps);
-        launch_ddim_update(ctx, xs, eps, cfg ? eps + a.B * per : nullptr, a.scale, cur_coef, (long long)a.B * per, xs,
-                           nullptr, d_step);
+        launch_ddim_step(ctx, xin, per, per_in, eps, cfg ? eps + a.B * per : nullptr, a.scale, cur_coef, (long long)a.B * per, xs,
+                         a.h_sigmas ? a.d_noise_p : nullptr, a.temperature, a.S, logging ? a.d_log_x : nullptr,
+                         logging ? a.d_log_x0 : nullptr, d_step);
     };
 
     // Everything a captured step depends on besides the device-side state it reads: the model and its own buffers, the
@@ -79,13 +95,23 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
     auto make_key = [&]() {
         std::vector<unsigned long long> k;
         unet.graph_key(k);
-        unsigned scale_bits;
+        unsigned scale_bits, temp_bits;
         static_assert(sizeof(scale_bits) == sizeof(a.scale), "float bits");
         std::memcpy(&scale_bits, &a.scale, 4);
+        std::memcpy(&temp_bits, &a.temperature, 4);
+        k.push_back(temp_bits);
         for (unsigned long long v : {(unsigned long long)a.S, (unsigned long long)a.B, (unsigned long long)a.C, (unsigned long long)a.H,
                                      (unsigned long long)a.W, (unsigned long long)a.Cc, (unsigned long long)a.L,
                                      (unsigned long long)cfg, (unsigned long long)concat, (unsigned long long)scale_bits,
                                      (unsigned long long)ctx.dtype, (unsigned long long)reinterpret_cast<uintptr_t>(slab),
+                                     // the caller's buffers the step's launches read or write besides the slab
+                                     (unsigned long long)reinterpret_cast<uintptr_t>(a.d_mask),
+                                     (unsigned long long)reinterpret_cast<uintptr_t>(a.d_x0),
+                                     (unsigned long long)reinterpret_cast<uintptr_t>(a.d_noise_q),
+                                     (unsigned long long)reinterpret_cast<uintptr_t>(a.h_sigmas ? a.d_noise_p : nullptr),
+                                     (unsigned long long)reinterpret_cast<uintptr_t>(logging ? a.d_log_x : nullptr),
+                                     (unsigned long long)reinterpret_cast<uintptr_t>(logging ? a.d_log_x0 : nullptr),
+                                     (unsigned long long)(a.h_sigmas ? 1 : 0),
                                      (unsigned long long)reinterpret_cast<uintptr_t>(ctx.stream),
                                      (unsigned long long)reinterpret_cast<uintptr_t>(ctx.ws.base()),
                                      (unsigned long long)ctx.ws.capacity()})

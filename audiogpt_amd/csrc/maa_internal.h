@@ -263,10 +263,16 @@ void launch_scale(const Ctx& ctx, const float* x, long long n, float s, float* o
 void launch_ddim_update(const Ctx& ctx, const float* x, const float* eps_u, const float* eps_c, float scale,
                         const float* coef, long long n, float* x_prev, float* pred_x0, int* step = nullptr);
 // UNet input of a step (latents duplicated for CFG when nB = 2B, or concatenated with the inpaint conditioning) and the
-// step's timestep / coefficient slots, selected from device tables by the device index *step
+// step's timestep / coefficient slots (8 floats per DDIM index: a_t, a_prev, sigma, sqrt(1-a_t), sqrt(ac_t), sqrt(1-ac_t), log
+// slot, 0), selected from device tables by the device index *step; mask / x0 / noise_q: the mask blend of ddim.py:147-150
 void launch_ddim_prepare(const Ctx& ctx, const float* x, const float* concat, int B, int nB, long long per,
                          long long per_c, const float* tab_t, const float* tab_coef, const int* step, float* xin,
-                         float* cur_t, float* cur_coef);
+                         float* cur_t, float* cur_coef, const float* mask = nullptr, const float* x0 = nullptr,
+                         const float* noise_q = nullptr, int S = 0);
+// the loop's update: x from the step's UNet input, optional sigma_t * noise * temperature, logged intermediates, index - 1
+void launch_ddim_step(const Ctx& ctx, const float* xin, long long per, long long per_in, const float* eps_u, const float* eps_c,
+                      float scale, const float* coef, long long n, float* x_prev, const float* noise_p, float temperature, int S,
+                      float* log_x, float* log_x0, int* step);
 // BigVGAN Activation1d on [B, L, C]: up2 FIR -> snake -> down2 FIR (replicate padding)
 void launch_snake_aa(const Ctx& ctx, const float* x, int B, int L, int C, const float* inv_beta, const float* alpha,
                      float* out);

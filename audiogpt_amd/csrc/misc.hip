@@ -136,24 +136,74 @@ __global__ void ddim_update_kernel(const float* x, const float* __restrict__ eu,
     }
 }
 
+// The sampling loop's form of the update (ddim.py:199, 210-225 in full): x is read from the step's UNet input (the first B
+// samples of xin hold the -- possibly mask-blended -- latent, per_in elements apart), noise = sigma_t * z * temperature with the
+// caller's z of this step (eta > 0), and the step's x_{t-1} / pred_x0 are copied into the log slabs when the device table
+// says this index is logged (ddim.py:161-163).  Term order as the reference: (sqrt(a_prev) x0 + dir e) + noise.
+__global__ void ddim_step_kernel(const float* __restrict__ xin, long long per, long long per_in, const float* __restrict__ eu,
+                                 const float* __restrict__ ec, float scale, const float* __restrict__ coef, long long n,
+                                 float* __restrict__ x_prev, const float* __restrict__ noise_p, float temperature, int S,
+                                 float* __restrict__ log_x, float* __restrict__ log_x0, int* __restrict__ step) {
+    // (the DDIM index comes from the step's coefficient slot, written by the prepare kernel: *step itself is decremented
+    //  below by one thread while other blocks may still be starting)
+    const int idx = (int)coef[7];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *step = idx - 1;
+    const float a_t = coef[0], a_prev = coef[1], sigma = coef[2], somat = coef[3];
+    const int slot = (int)coef[6];
+    const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev), dir = sqrtf(1.f - a_prev - sigma * sigma);
+    const float* z = noise_p ? noise_p + (long long)(S - 1 - idx) * n : nullptr;      // visiting order: i = S - 1 - index
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float e = eu[i];
+        if (ec) e = e + scale * (ec[i] - e);
+        const long long b = i / per;
+        const float xv = xin[b * per_in + (i - b * per)];
+        const float x0 = (xv - somat * e) / sqrt_at;
+        float xp = sqrt_ap * x0 + dir * e;
+        if (z) xp = xp + sigma * z[i] * temperature;
+        x_prev[i] = xp;
+        if (slot >= 0 && log_x) {
+            log_x[(long long)slot * n + i] = xp;
+            log_x0[(long long)slot * n + i] = x0;
+        }
+    }
+}
+
 // UNet input and scalars of one DDIM step, with nothing from the host: idx = *step selects the row of the device
 // tables; xin[b'] = cat(x[b' % B], concat[b' % B]) for b' < nB (nB = 2B duplicates the latents for CFG in the order
 // [uncond ; cond], ddim.py:177-179; concat is the inpaint model's conditioning, ddpm.py:1404-1406).
+// mask != null (ddim.py:147-150): the latent is first blended with the noised original,
+//   img = q_sample(x0, t) * mask + (1 - mask) * img,   q_sample = sqrt(ac_t) x0 + sqrt(1 - ac_t) z   (ddpm.py:272-275)
+// with the caller's z of this step; the blended latent only exists inside xin (the update kernel reads it from there).
 __global__ void ddim_prepare_kernel(const float* __restrict__ x, const float* __restrict__ concat, int B, int nB,
                                     long long per, long long per_c, const float* __restrict__ tab_t,
                                     const float* __restrict__ tab_coef, const int* __restrict__ step,
-                                    float* __restrict__ xin, float* __restrict__ cur_t, float* __restrict__ cur_coef) {
+                                    float* __restrict__ xin, float* __restrict__ cur_t, float* __restrict__ cur_coef,
+                                    const float* __restrict__ mask, const float* __restrict__ x0, const float* __restrict__ noise_q,
+                                    int S) {
     const int idx = *step;
     if (blockIdx.x == 0) {
         if (threadIdx.x < nB) cur_t[threadIdx.x] = tab_t[idx];
-        if (threadIdx.x < 4) cur_coef[threadIdx.x] = tab_coef[idx * 4 + threadIdx.x];
+        if (threadIdx.x < 8) cur_coef[threadIdx.x] = tab_coef[idx * 8 + threadIdx.x];
     }
+    const float sq_ac = tab_coef[idx * 8 + 4], sq_1mac = tab_coef[idx * 8 + 5];
+    const float* z = noise_q ? noise_q + (long long)(S - 1 - idx) * B * per : nullptr;
     const long long per_in = per + per_c, n = (long long)nB * per_in;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int bb = (int)(i / per_in);
         const long long r = i - bb * per_in;
         const int b = bb % B;
-        xin[i] = r < per ? x[b * per + r] : concat[b * per_c + (r - per)];
+        float v;
+        if (r < per) {
+            v = x[b * per + r];
+            if (mask) {
+                const long long e = b * per + r;
+                const float orig = sq_ac * x0[e] + sq_1mac * z[e];
+                v = orig * mask[e] + (1.f - mask[e]) * v;
+            }
+        } else {
+            v = concat[b * per_c + (r - per)];
+        }
+        xin[i] = v;
     }
 }
 
@@ -325,10 +375,16 @@ void launch_ddim_update(const Ctx& ctx, const float* x, const float* eps_u, cons
 }
 void launch_ddim_prepare(const Ctx& ctx, const float* x, const float* concat, int B, int nB, long long per,
                          long long per_c, const float* tab_t, const float* tab_coef, const int* step, float* xin,
-                         float* cur_t, float* cur_coef) {
+                         float* cur_t, float* cur_coef, const float* mask, const float* x0, const float* noise_q, int S) {
     MAA_CHECK(nB <= 256, "ddim: at most 256 UNet rows per step");
     MAA_LAUNCH1(ddim_prepare_kernel, (long long)nB * (per + per_c), x, concat, B, nB, per, per_c, tab_t, tab_coef, step,
-                xin, cur_t, cur_coef);
+                xin, cur_t, cur_coef, mask, x0, noise_q, S);
+}
+void launch_ddim_step(const Ctx& ctx, const float* xin, long long per, long long per_in, const float* eps_u, const float* eps_c,
+                      float scale, const float* coef, long long n, float* x_prev, const float* noise_p, float temperature, int S,
+                      float* log_x, float* log_x0, int* step) {
+    MAA_LAUNCH1(ddim_step_kernel, n, xin, per, per_in, eps_u, eps_c, scale, coef, n, x_prev, noise_p, temperature, S, log_x, log_x0,
+                step);
 }
 
 static std::once_flag g_fir_once[64];      // one upload of the FIR taps per device (thread-safe: contexts on several threads)

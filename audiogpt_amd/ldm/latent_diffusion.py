@@ -102,6 +102,10 @@ class LatentDiffusionAudio(object):
         self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32, device=self.device)
         self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1].astype(np.float64)), dtype=torch.float32,
                                                 device=self.device)
+        # ddpm.py:139-140: formed from the fp64 cumprod, stored as fp32 buffers (q_sample and the sampler's mask blend read them)
+        ac64 = np.cumprod(1.0 - betas, axis=0)
+        self.sqrt_alphas_cumprod = torch.tensor(np.sqrt(ac64), dtype=torch.float32, device=self.device)
+        self.sqrt_one_minus_alphas_cumprod = torch.tensor(np.sqrt(1.0 - ac64), dtype=torch.float32, device=self.device)
         self.scale_factor = float(self.cfg.get("scale_factor", 1.0))
         self.unet = self.vae = None
         # conditioning encoder: the caller's; else the device towers when the checkpoint carries their weights
@@ -118,6 +122,13 @@ class LatentDiffusionAudio(object):
             for k, v in WT.make_vae_state_dict(self.cfg["vae"], seed=seeds[1]).items():
                 state_dict["first_stage_model." + k] = v
         self.load_state_dict(state_dict, strict=False)
+
+    def q_sample(self, x_start, t, noise=None):
+        """ddpm.py:272-275: the forward process at (integer tensor) timestep t."""
+        noise = torch.randn_like(x_start) if noise is None else noise
+        shape = (t.shape[0],) + (1,) * (x_start.dim() - 1)
+        return (self.sqrt_alphas_cumprod.gather(-1, t).reshape(shape) * x_start +
+                self.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(shape) * noise)
 
     # ---- nn.Module-like surface the tools touch ---------------------------------------------------
     def load_state_dict(self, sd, strict=False):

@@ -126,7 +126,8 @@ int maa_unet_forward(maa_ctx* ctx, maa_unet* u, const float* d_x, const float* d
 int maa_ddim_update(maa_ctx* ctx, const float* d_x, const float* d_eps_uncond, const float* d_eps_cond, float scale,
                     const float* d_coef, int64_t n, float* d_x_prev, float* d_pred_x0);
 
-/* replaces: DDIMSampler.ddim_sampling (ddim.py:118-166) for the tools' call pattern (eta = 0, no mask):
+/* replaces: DDIMSampler.ddim_sampling (ddim.py:118-166), including mask / x0 blending, eta > 0 with the caller's noise and
+ * the logged intermediates (score correctors, quantisation, dropout noise and host callbacks are not covered):
  * runs S steps on the device without host round trips.
  *   d_x [B, C, H, W] in/out latent (x_T in, x_0 out)
  *   d_cond / d_uncond [B, L, context_dim] (crossattn; d_uncond NULL or scale == 1 -> no CFG), or for the
@@ -144,6 +145,26 @@ typedef struct maa_ddim_args {
     const float* h_alphas;
     const float* h_alphas_prev;
     int use_graph;          /* capture one step into a hipGraph and replay it */
+    /* ---- the rest of DDIMSampler.sample's signature (ddim.py:59-115); all optional (NULL / 0) ----
+     * mask / x0 (ddim.py:147-150): before every step img = q_sample(x0, t) * mask + (1 - mask) * img, with
+     *   q_sample = h_sqrt_ac[i] x0 + h_sqrt_1mac[i] z (ddpm.py:272-275); d_mask, d_x0 [B, C, H, W]; d_noise_q [S][B, C, H, W] =
+     *   the S draws of randn_like(x0) in the order the loop makes them (first step first) */
+    const float* d_mask;
+    const float* d_x0;
+    const float* d_noise_q;
+    const float* h_sqrt_ac;      /* [S] sqrt(alphas_cumprod[t_i]), sqrt(1 - alphas_cumprod[t_i]) per DDIM index, fp32 as the */
+    const float* h_sqrt_1mac;    /*     model's buffers hold them (ddpm.py:139-140) */
+    /* eta > 0 (ddim.py:210-225): x_prev += sigma_t * z * temperature; h_sigmas [S] per DDIM index as make_schedule forms them,
+     *   d_noise_p [S][B, C, H, W] = the S draws of noise_like(x.shape) in loop order */
+    const float* h_sigmas;
+    const float* d_noise_p;
+    float temperature;
+    /* intermediates (ddim.py:158-163): after the step of DDIM index i with i % log_every_t == 0 or i == S - 1 the new latent and
+     *   pred_x0 are copied to d_log_x / d_log_x0 [n_log][B, C, H, W], in loop order; n_log must equal the number of such steps */
+    int log_every_t;
+    int n_log;
+    float* d_log_x;
+    float* d_log_x0;
 } maa_ddim_args;
 int maa_ddim_sample(maa_ctx* ctx, maa_unet* u, const maa_ddim_args* args, float* d_x);
 

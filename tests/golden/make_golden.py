@@ -140,6 +140,68 @@ def ddim_case(name, unet, cfg, manifest, S=10, scale=1.5, seed=0):
     return z
 
 
+def ddim_full_signature_case(name, unet, S=6, scale=1.5, eta=0.5, temperature=0.9, log_every_t=2, seed=31):
+    """The rest of DDIMSampler.sample's signature on the T2A model: mask / x0 blending (ddim.py:147-150), eta > 0 with
+    temperature (:210-225) and the intermediates every log_every_t steps (:158-163).  The sampler draws its per-step noise from
+    torch's global RNG; the same draws are repeated afterwards from the same seed and stored (loop order), with the sampler's
+    own sigma table and the q_sample buffers."""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.util import extract_into_tensor, make_beta_schedule
+    ldm = C.LDM_T2A
+
+    class Shim:
+        def __init__(self):
+            betas = make_beta_schedule("linear", ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+            ac = np.cumprod(1.0 - betas, axis=0)
+            self.num_timesteps = ldm["timesteps"]
+            self.betas = torch.tensor(betas, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+            # ddpm.py:139-140 (the DDPM class itself needs pytorch_lightning, which is not installed)
+            self.sqrt_alphas_cumprod = torch.tensor(np.sqrt(ac), dtype=torch.float32)
+            self.sqrt_one_minus_alphas_cumprod = torch.tensor(np.sqrt(1.0 - ac), dtype=torch.float32)
+            self.device = torch.device("cpu")
+
+        def q_sample(self, x_start, t, noise=None):          # ddpm.py:272-275, verbatim semantics
+            noise = torch.randn_like(x_start) if noise is None else noise
+            return (extract_into_tensor(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start +
+                    extract_into_tensor(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise)
+
+        def apply_model(self, x, t, c):
+            return unet(x, t, context=c)
+
+    shim = Shim()
+    sampler = DDIMSampler(shim)
+    sampler.device = torch.device("cpu")
+    n = 2
+    x_T = torch.from_numpy(np.random.RandomState(56).randn(n, 4, 10, 78)).float()
+    g = torch.Generator().manual_seed(78)
+    x0 = torch.randn(n, 4, 10, 78, generator=g)
+    mask = torch.zeros(n, 1, 10, 78)
+    mask[0, :, :, 20:45] = 1.0
+    mask[1, :, 2:7, 50:] = 1.0
+    c, uc = _cond(n, 77, 1234), _cond(n, 77, 1235)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        z, inter = sampler.sample(S=S, conditioning=c, batch_size=n, shape=[4, 10, 78], verbose=False, eta=eta, mask=mask, x0=x0,
+                                  temperature=temperature, unconditional_guidance_scale=scale, unconditional_conditioning=uc,
+                                  x_T=x_T, log_every_t=log_every_t)
+    torch.manual_seed(seed)
+    nq, npp = [], []
+    for _ in range(len(sampler.ddim_timesteps)):          # (S = 6 -> range(0, 1000, 166) = seven steps)
+        nq.append(torch.randn_like(x0))
+        npp.append(torch.randn(x_T.shape))
+    steps = np.asarray(sampler.ddim_timesteps)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), x_T=x_T.numpy(), x0=x0.numpy(), mask=mask.numpy(), c=c.numpy(), uc=uc.numpy(),
+                        noise_q=torch.stack(nq).numpy(), noise_p=torch.stack(npp).numpy(), z=z.numpy(),
+                        x_inter=np.stack([t.numpy() for t in inter["x_inter"]]),
+                        pred_x0=np.stack([t.numpy() for t in inter["pred_x0"]]),
+                        ddim_timesteps=steps, ddim_sigmas=np.asarray(sampler.ddim_sigmas, dtype=np.float64),
+                        sqrt_ac=shim.sqrt_alphas_cumprod.numpy()[steps], sqrt_1mac=shim.sqrt_one_minus_alphas_cumprod.numpy()[steps],
+                        S=S, scale=scale, eta=eta, temperature=temperature, log_every_t=log_every_t, seed=seed)
+    print(name, "z std", float(z.std()), "logged", len(inter["x_inter"]))
+
+
 def ddim_variant_case(name, unet, ldm, S, scale, ctx_len=None):
     """The reference DDIMSampler on the other two tools' call patterns:
     inpaint -- conditioning_key 'concat' (ddpm.py:1404-1406: unet(cat([x] + [c], 1), t)), no guidance (audio-chatgpt.py:513-518);
@@ -878,6 +940,7 @@ def main():
     u_inp = unet_case("unet_inpaint", C.UNET_INPAINT, 10, 106, 0, manifest, n=1, seed=5)
     ddim_variant_case("ddim_i2a_s4", u_i2a, C.LDM_I2A, 4, 3.0, ctx_len=1)
     ddim_variant_case("ddim_inpaint_s4", u_inp, C.LDM_INPAINT, 4, 1.0)
+    ddim_full_signature_case("ddim_t2a_mask_eta_s6", unet)
     mel = vae_case("vae", C.VAE_DDCONFIG, manifest, z=z)
     # plumbing config 1 end to end: clamp((x+1)/2, 0, 1) -> vocoder (audio-chatgpt.py:176-181)
     spec = torch.clamp((mel + 1.0) / 2.0, 0.0, 1.0)[:, 0]
@@ -920,6 +983,13 @@ def main_nsf_only():
     print("torch", torch.__version__)
 
 
+def main_ddim_full_only():
+    """`python tests/golden/make_golden.py ddimfull`: the mask / eta / intermediates case of the sampler only."""
+    _install_shims()
+    u = unet_case("unet_t2a", C.UNET_T2A, 10, 78, 77, {}, save=False)
+    ddim_full_signature_case("ddim_t2a_mask_eta_s6", u)
+
+
 def main_ddim_variants_only():
     """`python tests/golden/make_golden.py ddimvar`: add the I2A / inpaint sampler cases only."""
     torch.set_num_threads(8)
@@ -933,5 +1003,5 @@ def main_ddim_variants_only():
 
 
 if __name__ == "__main__":
-    {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "diffsinger": main_diffsinger_only,
+    {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "ddimfull": main_ddim_full_only, "diffsinger": main_diffsinger_only,
      "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only, "cliptext": main_clip_text_only, "clapaudio": main_clap_audio_only, "clapscore": main_clap_score_only, "mixed": main_mixed_only}.get(" ".join(sys.argv[1:]), main)()

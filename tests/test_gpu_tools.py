@@ -72,6 +72,58 @@ def test_ddim_sampler_and_model_surface_match_reference(golden, precision):
         sampler.sample(S=2, conditioning=c[:, :, :512], batch_size=1, shape=[4, 10, 78], verbose=False, x_T=x_T)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_ddim_sampler_mask_eta_intermediates_match_reference(golden, precision):
+    """The rest of DDIMSampler.sample's signature on the device loop: mask / x0 blending (ddim.py:147-150), eta = 0.5 with
+    temperature 0.9 (:210-225) and x_inter / pred_x0 every log_every_t = 2 steps (:158-163), against the reference sampler's
+    own run (tests/golden/make_golden.py ddimfull: its RNG draws were recorded and are replayed here); graph replay == eager;
+    and with a seeded global RNG the wrapper draws what the reference's loop would."""
+    from audiogpt_amd.ldm.ddim import DDIMSampler
+    from audiogpt_amd.ldm.latent_diffusion import LatentDiffusionAudio
+    g = golden("ddim_t2a_mask_eta_s6")
+    model = LatentDiffusionAudio(C.LDM_T2A, device="cuda:0", precision=precision)
+    sampler = DDIMSampler(model)
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    kw = dict(S=int(g["S"]), conditioning=t("c"), batch_size=2, shape=[4, 10, 78], verbose=False, eta=float(g["eta"]),
+              mask=t("mask"), x0=t("x0"), temperature=float(g["temperature"]), unconditional_guidance_scale=float(g["scale"]),
+              unconditional_conditioning=t("uc"), x_T=t("x_T"), log_every_t=int(g["log_every_t"]))
+    z, inter = sampler.sample(_step_noise=(t("noise_q"), t("noise_p")), **kw)
+    assert list(sampler.ddim_timesteps) == list(g["ddim_timesteps"]) and len(sampler.ddim_timesteps) == 7      # S = 6 -> 7 steps
+    assert np.array_equal(np.asarray(sampler.ddim_sigmas, dtype=np.float32), g["ddim_sigmas"].astype(np.float32))
+    assert np.array_equal(model.sqrt_alphas_cumprod.cpu().numpy()[g["ddim_timesteps"]], g["sqrt_ac"])
+    assert len(inter["x_inter"]) == g["x_inter"].shape[0] and len(inter["pred_x0"]) == g["pred_x0"].shape[0]
+    tol = 2e-3 if precision == "bf16x3" else 1e-3          # (the tolerance of the plain 10-step sampler test above)
+    check(f"tools_{precision}_DDIMSampler.sample_mask_eta_z", z, g["z"], tol)
+    for i in range(len(inter["x_inter"])):
+        check(f"tools_{precision}_DDIMSampler.x_inter{i}", inter["x_inter"][i], g["x_inter"][i], tol)
+        check(f"tools_{precision}_DDIMSampler.pred_x0{i}", inter["pred_x0"][i], g["pred_x0"][i], tol)
+    # hipGraph replay == eager, bit for bit
+    zg = model.unet.ddim_sample(t("x_T"), sampler.ddim_timesteps, sampler.ddim_alphas.numpy(), sampler.ddim_alphas_prev,
+                                cond=t("c"), uncond=t("uc"), scale=float(g["scale"]), mask=t("mask"), x0=t("x0"), noise_q=t("noise_q"),
+                                sqrt_ac=g["sqrt_ac"], sqrt_1mac=g["sqrt_1mac"], sigmas=np.asarray(sampler.ddim_sigmas, dtype=np.float32),
+                                noise_p=t("noise_p"), temperature=float(g["temperature"]), use_graph=False)
+    assert torch.equal(zg, z)
+    # seeded: the wrapper consumes the generator as the reference's loop does (q_sample's randn_like, then noise_like, per step)
+    torch.manual_seed(123)
+    z1, _ = sampler.sample(**kw)
+    torch.manual_seed(123)
+    nq, npp = [], []
+    for _ in range(7):
+        nq.append(torch.randn(2, 4, 10, 78, device="cuda"))
+        npp.append(torch.randn(2, 4, 10, 78, device="cuda"))
+    after = torch.randn(3, device="cuda")
+    z2, _ = sampler.sample(_step_noise=(torch.stack(nq), torch.stack(npp)), **kw)
+    assert torch.equal(z1, z2)
+    torch.manual_seed(123)
+    sampler.sample(**kw)
+    assert torch.equal(torch.randn(3, device="cuda"), after)
+    # what still has no device form says so
+    with pytest.raises(NotImplementedError):
+        sampler.sample(noise_dropout=0.1, **kw)
+    with pytest.raises(AssertionError):
+        sampler.sample(**dict(kw, x0=None))
+
+
 # ------------------------------------------------------------------------------------------------ T2A
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_T2A_txt2audio_matches_oracle_chain(precision):

@@ -181,6 +181,39 @@ def test_ddim_inpaint_concat_matches_reference(golden):
     assert np.abs(z.numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
 
 
+def test_ddim_mask_eta_intermediates_match_reference(golden):
+    """The rest of DDIMSampler.sample's signature (ddim.py:147-150 mask / x0 blend through q_sample, :210-225 eta > 0 with
+    temperature, :158-163 intermediates every log_every_t): the reference sampler's run with its own RNG draws recorded."""
+    g = golden("ddim_t2a_mask_eta_s6")
+    cfg, ldm = C.UNET_T2A, C.LDM_T2A
+    sd = WT.make_unet_state_dict(cfg, seed=0)
+    ac = O_ddim.alphas_cumprod(ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+    S, eta = int(g["S"]), float(g["eta"])
+    steps = O_ddim.ddim_timesteps(S)
+    assert steps.tolist() == g["ddim_timesteps"].tolist()
+    # the sigma table in the reference's mixed fp32 / fp64 arithmetic, and the q_sample buffers
+    _, _, sig, _ = O_ddim.ddim_tables(ac, steps, eta)
+    assert np.array_equal(sig.numpy(), g["ddim_sigmas"].astype(np.float32))
+    # q_sample's buffers come from the fp64 cumprod (ddpm.py:139-140); rebuilt from the fp32 buffer they are within an fp32 ulp
+    sq, sq1 = O_ddim.q_sample_tables(ac, steps)
+    assert np.abs(sq.numpy() - g["sqrt_ac"]).max() <= 1.2e-7 and np.abs(sq1.numpy() - g["sqrt_1mac"]).max() <= 1.2e-7
+    from audiogpt_amd.pipeline import make_beta_schedule_linear
+    ac64 = np.cumprod(1.0 - make_beta_schedule_linear(ldm["timesteps"], ldm["linear_start"], ldm["linear_end"]), axis=0)
+    assert np.array_equal(np.sqrt(ac64).astype(np.float32)[steps], g["sqrt_ac"])               # what LatentDiffusionAudio registers
+    assert np.array_equal(np.sqrt(1.0 - ac64).astype(np.float32)[steps], g["sqrt_1mac"])
+    t = lambda k: torch.from_numpy(g[k])
+    with torch.no_grad():
+        z, inter = O_ddim.ddim_sample(lambda x, ts, c: O_unet.unet_forward(sd, cfg, x, ts, c), ac, S, t("x_T"), t("c"), t("uc"),
+                                      scale=float(g["scale"]), eta=eta, mask=t("mask"), x0=t("x0"), noise_q=t("noise_q"),
+                                      noise_p=t("noise_p"), temperature=float(g["temperature"]), log_every_t=int(g["log_every_t"]),
+                                      q_tables=(t("sqrt_ac"), t("sqrt_1mac")))
+    assert len(inter["x_inter"]) == g["x_inter"].shape[0] == len(inter["pred_x0"]) == g["pred_x0"].shape[0]
+    for i in range(len(inter["x_inter"])):
+        _close(inter["x_inter"][i].numpy(), g["x_inter"][i], 2e-4, f"x_inter {i}")
+        _close(inter["pred_x0"][i].numpy(), g["pred_x0"][i], 2e-4, f"pred_x0 {i}")
+    _close(z.numpy(), g["z"], 2e-4, "z")
+
+
 def test_diffsinger_denoiser_and_plms_loop_match_reference(golden):
     """Groundwork for SURVEY 8f/N2: oracle/diffsinger.py against the reference DiffNet and GaussianDiffusion.p_sample_plms
     (6 PLMS steps: the 2-evaluation warm-up step, then the 2nd/3rd/4th-order multistep formulas)."""
