@@ -95,7 +95,7 @@ EXPORTS = [
     "maa_last_error", "maa_version", "maa_ctx_create", "maa_ctx_destroy", "maa_ctx_synchronize",
     "maa_ctx_set_stream", "maa_ctx_set_precision", "maa_ctx_reload_tuning", "maa_ctx_workspace_bytes", "maa_prof_begin", "maa_prof_end", "maa_unet_create", "maa_unet_destroy",
     "maa_unet_set_context", "maa_unet_forward", "maa_ddim_update", "maa_ddim_sample", "maa_vae_create",
-    "maa_vae_destroy", "maa_vae_decode", "maa_vae_encode_moments", "maa_vocoder_create", "maa_vocoder_destroy",
+    "maa_vae_destroy", "maa_vae_decode", "maa_vae_decode_spec", "maa_vae_encode_moments", "maa_vocoder_create", "maa_vocoder_destroy",
     "maa_vocoder_forward", "maa_vocoder_forward_f0", "maa_diffnet_create", "maa_diffnet_destroy", "maa_diffnet_forward",
     "maa_plms_sample", "maa_encoder_create", "maa_encoder_destroy", "maa_encoder_text", "maa_encoder_image",
     "maa_encoder_text_cls", "maa_clap_audio_create", "maa_clap_audio_destroy", "maa_clap_audio_embed", "maa_clap_similarity",
@@ -140,6 +140,7 @@ def load():
         "maa_vae_create": [vp, C.POINTER(maa_vae_config), C.POINTER(maa_tensor), ci, C.POINTER(vp)],
         "maa_vae_destroy": [vp],
         "maa_vae_decode": [vp, vp, vp, ci, ci, ci, cf, vp],
+        "maa_vae_decode_spec": [vp, vp, vp, ci, ci, ci, cf, vp],
         "maa_vae_encode_moments": [vp, vp, vp, ci, ci, ci, vp],
         "maa_vocoder_create": [vp, C.POINTER(maa_vocoder_config), C.POINTER(maa_tensor), ci, C.POINTER(vp)],
         "maa_vocoder_destroy": [vp],

@@ -412,6 +412,17 @@ class VAE:
                                                 L.dptr(mel)))
         return mel
 
+    def decode_spec(self, z, scale_factor=1.0):
+        """decode_first_stage + the tools' clamp((x + 1) / 2, 0, 1) in the decoder's last pass: z [B,4,h,w] -> spec [B,8h,8w]."""
+        z = _f32(z, self.ctx.device)
+        B, _, h, w = z.shape
+        f = 2 ** (len(self.dd["ch_mult"]) - 1)
+        spec = torch.empty(B, h * f, w * f, device=self.ctx.device)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_vae_decode_spec(self.ctx.h, self.h, L.dptr(z), B, h, w, 1.0 / float(scale_factor),
+                                                     L.dptr(spec)))
+        return spec
+
     def encode_moments(self, mel):
         """AutoencoderKL.encode moments (autoencoder.py:345-349): mel [B,1,H,W] -> [B, 2*embed, H/8, W/8]."""
         mel = _f32(mel, self.ctx.device)

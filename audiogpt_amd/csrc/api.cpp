@@ -277,6 +277,13 @@ int maa_vae_decode(maa_ctx* ctx, maa_vae* v, const float* d_z, int B, int h, int
         v->m->decode(ctx->c, d_z, B, h, w, inv_scale, d_mel);
     });
 }
+int maa_vae_decode_spec(maa_ctx* ctx, maa_vae* v, const float* d_z, int B, int h, int w, float inv_scale, float* d_spec) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(v && d_z && d_spec && B > 0 && h > 0 && w > 0, "bad vae_decode_spec arguments");
+        v->m->decode_spec(ctx->c, d_z, B, h, w, inv_scale, d_spec);
+    });
+}
 int maa_vae_encode_moments(maa_ctx* ctx, maa_vae* v, const float* d_mel, int B, int H, int W, float* d_moments) {
     return guarded([&] {
         bind(ctx);

@@ -284,6 +284,7 @@ void launch_similarity(const Ctx& ctx, const float* audio, const float* text, in
 void launch_leaky(const Ctx& ctx, const float* x, long long n, float slope, float* out);
 void launch_clamp_affine(const Ctx& ctx, const float* x, long long n, float mul, float add, float lo, float hi,
                          float* out);
+void launch_spec_from_mel(const Ctx& ctx, const float* mel, long long n, float* spec);      // clamp((mel + 1) / 2, 0, 1)
 
 // box calibration (calib.hip): kind 0 -> dense bf16 MFMA TFLOP/s of a fixed register-only loop, kind 1 -> GB/s of a 256 MiB copy
 double calib_run(const Ctx& ctx, int kind);

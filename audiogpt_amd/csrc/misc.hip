@@ -90,6 +90,13 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int B, int C, i
     }
 }
 
+// clamp((mel + 1) / 2, 0, 1): the line between decode_first_stage and the vocoder in every tool (audio-chatgpt.py:175-176,
+// 254-255, 521-522), in the reference's operation order
+__global__ void spec_from_mel_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = fminf(fmaxf((x[i] + 1.0f) / 2.0f, 0.0f), 1.0f);
+}
+
 __global__ void avgpool2_kernel(const float* __restrict__ x, int B, int H, int W, int C, float* __restrict__ out) {
     const int Ho = H / 2, Wo = W / 2;
     const long long n = (long long)B * Ho * Wo * C;
@@ -356,6 +363,9 @@ void launch_scale(const Ctx& ctx, const float* x, long long n, float s, float* o
 void launch_clamp_affine(const Ctx& ctx, const float* x, long long n, float mul, float add, float lo, float hi,
                          float* out) {
     MAA_LAUNCH1(clamp_affine_kernel, n, x, n, mul, add, lo, hi, out);
+}
+void launch_spec_from_mel(const Ctx& ctx, const float* mel, long long n, float* spec) {
+    MAA_LAUNCH1(spec_from_mel_kernel, n, mel, n, spec);
 }
 void launch_nchw_to_nhwc(const Ctx& ctx, const float* x, int B, int C, int HW, float* out) {
     MAA_LAUNCH1(nchw_to_nhwc_kernel, (long long)B * C * HW, x, B, C, HW, out);

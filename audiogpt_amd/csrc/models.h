@@ -35,6 +35,8 @@ public:
     VAE(const maa_vae_config& cfg, const StateDict& sd, int precision);
     ~VAE();
     void decode(Ctx& ctx, const float* z_nchw, int B, int h, int w, float inv_scale, float* mel_nchw);
+    // decode + the tools' clamp((mel + 1) / 2, 0, 1) (audio-chatgpt.py:175-176) in the last pass: spec [B, 8h, 8w]
+    void decode_spec(Ctx& ctx, const float* z_nchw, int B, int h, int w, float inv_scale, float* spec);
     void encode_moments(Ctx& ctx, const float* mel_nchw, int B, int H, int W, float* moments_nchw);
     const maa_vae_config& config() const;
 

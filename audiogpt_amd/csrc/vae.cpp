@@ -199,7 +199,8 @@ struct VAE::Impl {
         return out;
     }
 
-    void decode(Ctx& ctx, const float* z_nchw, int B, int h, int w, float inv_scale, float* mel_nchw) {
+    // spec = true: the tools' next line folded in -- clamp((mel + 1) / 2, 0, 1) (audio-chatgpt.py:175-176), written as [B, H, W]
+    void decode(Ctx& ctx, const float* z_nchw, int B, int h, int w, float inv_scale, float* mel_nchw, bool spec = false) {
         const int nres = cfg.n_ch_mult;
         T4 z = alloc_t(ctx, B, h, w, cfg.embed_dim);
         launch_nchw_to_nhwc(ctx, z_nchw, B, cfg.embed_dim, h * w, z.p);
@@ -235,7 +236,12 @@ struct VAE::Impl {
                          hn.p, hn.split);
         T4 out = alloc_t(ctx, B, hcur.H, hcur.W, cfg.out_ch);
         conv_into(ctx, hn, nullptr, d_conv_out, o3, out);
-        launch_nhwc_to_nchw(ctx, out.p, B, cfg.out_ch, hcur.H * hcur.W, mel_nchw, cfg.out_ch);
+        if (spec) {
+            MAA_CHECK(cfg.out_ch == 1, "decode_spec: the mel decoder has one output channel");
+            launch_spec_from_mel(ctx, out.p, (long long)B * hcur.H * hcur.W, mel_nchw);
+        } else {
+            launch_nhwc_to_nchw(ctx, out.p, B, cfg.out_ch, hcur.H * hcur.W, mel_nchw, cfg.out_ch);
+        }
     }
 
     void encode(Ctx& ctx, const float* mel_nchw, int B, int H, int W, float* moments_nchw) {
@@ -293,6 +299,10 @@ const maa_vae_config& VAE::config() const { return impl_->cfg; }
 void VAE::decode(Ctx& ctx, const float* z, int B, int h, int w, float inv_scale, float* mel) {
     PrecisionGuard pg(ctx, impl_->precision);
     run_sized(ctx, [&] { impl_->decode(ctx, z, B, h, w, inv_scale, mel); });
+}
+void VAE::decode_spec(Ctx& ctx, const float* z, int B, int h, int w, float inv_scale, float* spec) {
+    PrecisionGuard pg(ctx, impl_->precision);
+    run_sized(ctx, [&] { impl_->decode(ctx, z, B, h, w, inv_scale, spec, true); });
 }
 void VAE::encode_moments(Ctx& ctx, const float* mel, int B, int H, int W, float* moments) {
     PrecisionGuard pg(ctx, impl_->precision);

@@ -181,6 +181,9 @@ int maa_vae_destroy(maa_vae* v);
 /* replaces: LatentDiffusion_audio.decode_first_stage (ddpm_audio.py:352-359) -> AutoencoderKL.decode
  * (autoencoder.py:351-354): d_z [B, 4, h, w] -> d_mel [B, out_ch, 8h, 8w]; inv_scale = 1/scale_factor */
 int maa_vae_decode(maa_ctx* ctx, maa_vae* v, const float* d_z, int B, int h, int w, float inv_scale, float* d_mel);
+/* replaces: decode_first_stage followed by the tools' `torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0)` (audio-chatgpt.py:175-176,
+ * 254-255, 521-522): d_z [B, 4, h, w] -> d_spec [B, 8h, 8w] in [0, 1], what the vocoders take (one-channel decoders only) */
+int maa_vae_decode_spec(maa_ctx* ctx, maa_vae* v, const float* d_z, int B, int h, int w, float inv_scale, float* d_spec);
 /* replaces: AutoencoderKL.encode's moments (autoencoder.py:345-349): d_mel [B, 1, H, W] ->
  * d_moments [B, 2*embed_dim, H/8, W/8] = (mean | logvar, unclamped) */
 int maa_vae_encode_moments(maa_ctx* ctx, maa_vae* v, const float* d_mel, int B, int H, int W, float* d_moments);

@@ -119,6 +119,9 @@ def test_vae_decode_and_encode_match_reference(golden, vae):
     assert l1 <= 1e-4
     mom = vae.encode_moments(torch.from_numpy(g["mel_in"]))
     check("vae_encode_vs_reference", mom, g["moments"], 2e-4)
+    # the tools' clamp((x + 1) / 2, 0, 1) folded into the decoder's last pass: the same values bit for bit, [B, 80, T]
+    spec = vae.decode_spec(torch.from_numpy(g["z"]), 1.0)
+    assert torch.equal(spec, torch.clamp((mel + 1.0) / 2.0, min=0.0, max=1.0)[:, 0])
 
 
 @pytest.mark.parametrize("name,cfg", [("hifigan_16k_t2a", C.HIFIGAN_16K), ("hifigan_ns512", C.HIFIGAN_NS_512),
