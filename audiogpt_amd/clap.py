@@ -64,7 +64,10 @@ class CLAPWrapper:
     points: `state_dict=` instead of a checkpoint path, `tokenizer=`, `ctx=` to share a backend context)."""
 
     def __init__(self, model_fp=None, config_path=None, use_cuda=True, state_dict=None, tokenizer=None, ctx=None,
-                 device="cuda:0", precision=None, seed=21, crop_start=None):
+                 device="cuda:0", precision=None, seed=21, crop_start=None, synthetic=None):
+        """synthetic=True: seeded random weights of the CLAP architecture (benchmarks and tests -- its scores mean nothing).
+        Without it a wrapper built with neither `model_fp` nor `state_dict` still gets them, but says so loudly: the reference
+        always loads CLAP_weights_2022.pth (audio-chatgpt.py:146)."""
         self.args = dict(C.CLAP_SCORER)
         self.ctx = ctx or Context(device, precision=precision or default_precision())
         self.device = self.ctx.device
@@ -74,6 +77,10 @@ class CLAPWrapper:
         if state_dict is None and model_fp is not None:
             state_dict = torch.load(model_fp, map_location="cpu")["model"]                    # (:62)
         if state_dict is None:                                                                # no checkpoint ships: seeded weights
+            if not synthetic:
+                import warnings
+                warnings.warn("CLAPWrapper: no checkpoint (model_fp / state_dict) given -- using SEEDED RANDOM weights; the "
+                              "best-of-n ranking they produce is meaningless.  Pass synthetic=True to silence this.", stacklevel=2)
             state_dict = {"caption_encoder." + k: v for k, v in WT.make_clap_text_state_dict(self.args["text"], seed).items()}
             state_dict.update({"audio_encoder." + k: v
                                for k, v in WT.make_clap_audio_state_dict(self.args["audio"], seed + 1).items()})
@@ -112,9 +119,12 @@ class CLAPWrapper:
         """CLAPWrapper.resample_and_duration (:103-128) on the device -> 1-D tensor of audio_duration * sample_rate samples
         (sample_rate = the INPUT rate, as upstream)."""
         audio_time_series, sample_rate = wav_sr
-        x = torch.as_tensor(audio_time_series, dtype=torch.float32).to(self.device).reshape(1, -1)
+        # CLAPWrapper.py:103-110: T.Resample runs on the [channels, n] tensor, THEN everything is flattened (a stereo file's
+        # channels are filtered one by one and concatenated; mono -- what T2A produces -- is unaffected)
+        x = torch.as_tensor(audio_time_series, dtype=torch.float32).to(self.device)
+        x = x.reshape(1, -1) if x.dim() < 2 else x.reshape(-1, x.shape[-1])
         if resample and int(sample_rate) != self.args["sampling_rate"]:
-            x = self._resampler(int(sample_rate)).forward(x)
+            x = self._resampler(int(sample_rate)).forward(x.contiguous())
         x = x.reshape(-1)
         want = int(audio_duration * sample_rate)
         if want >= x.shape[0]:

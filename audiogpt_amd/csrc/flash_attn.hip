@@ -35,7 +35,7 @@ struct FlashArgs {
     float* out;
     int ldo;
     int out_split;                // write split32 lines (the to_out projection reads them with no conversion)
-    int precise_exp;              // MAA_FLASH_PRECISE_EXP=1: libm expf instead of v_exp_f32 (A/B timing)
+    int precise_exp;              // 1: libm expf instead of v_exp_f32 (kept for experiments; the library always passes 0)
     int causal;                   // query i sees keys 0 .. i only (OpenCLIP's text tower)
     long long o_bs;
     const float* zeros;
@@ -406,8 +406,7 @@ bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, co
     a.out = out;
     a.ldo = ldo;
     a.out_split = out_split;
-    static const int precise_exp = std::getenv("MAA_FLASH_PRECISE_EXP") ? 1 : 0;
-    a.precise_exp = precise_exp;
+    a.precise_exp = 0;      // (v_exp_f32 path; the libm variant was an A/B knob, retired in round 4)
     a.causal = causal;
     a.o_bs = (long long)Nq * ldo;
     a.zeros = ctx.zeros;

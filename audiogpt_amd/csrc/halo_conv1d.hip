@@ -253,7 +253,7 @@ void launch_c(const Ctx& ctx, const HaloArgs& a) {
 // uses the generic implicit GEMM.  MAA_NO_HALO=1 disables it (A/B, bit-identity tests).
 bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, const PackedW& w, int k, int dil, float slope,
                         const float* res, float out_scale, int accumulate, float* out) {
-    static const bool off = std::getenv("MAA_NO_HALO") != nullptr;
+    const bool off = ctx.tune.no_halo;
     // (C = 128 was tried with a 128-position tile, one workgroup per CU: 72.3 ms vs 70.6 ms for the generic engine on the
     //  config-3 stage -- at that width the layer is MFMA-bound and gains nothing from the staging; not kept)
     if (off || ctx.dtype != 1 || !(C == 32 || C == 64) || w.N != C || w.K != k * C || !w.split || !w.nk) return false;

@@ -406,7 +406,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     } else {
         cfg = choose_tile(p.M, ncols, p.Z, true);
     }
-    static const bool no_dma = std::getenv("MAA_NO_DMA") != nullptr;      // tests: same arithmetic, register staging
+    const bool no_dma = ctx.tune.no_dma;      // tests: same arithmetic, register staging
     const bool dma = terms == 3 && p.a_split && p.b_split && cfg < 3 && !no_dma;
     const PPPlan planp = dma ? igemm_pp_plan(ctx, p) : PPPlan();
     if (planp.bn) {
@@ -484,9 +484,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         pname = shape_name;
     }
     ProfScope prof(ctx, pname, flops, bytes);
-    static const int m_fastest = std::getenv("MAA_TILE_ORDER") ? std::atoi(std::getenv("MAA_TILE_ORDER")) : 0;
-    IGemm q = p;
-    q.m_fastest = m_fastest && p.Z == 1;
+    IGemm q = p;      // (tile order: N-tiles fastest inside an XCD's range -- M-fastest measured +4 % step time and was retired)
     if (dma)
         launch_igemm_dma(ctx, q, cfg, Nb);
     else if (terms == 3)

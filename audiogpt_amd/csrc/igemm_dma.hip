@@ -250,23 +250,12 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
 // about two workgroups per CU and K is long (the 10x78-resolution convolutions); two LDS stages (more workgroups per
 // CU) beat deeper copy queues except when there is only about one workgroup per CU (the 3x20-resolution layers).
 int igemm_dma_tile(const IGemm& p, int cfg) {
-    static const bool cfg_forced = std::getenv("MAA_FORCE_CFG") != nullptr || std::getenv("MAA_DMA_NOWIDEN") != nullptr;
     const long long ncols = (long long)p.N * (p.geglu ? 2 : 1);
-    if (cfg == 2 && !cfg_forced && p.K >= 1024 && ((p.M + 127) / 128) * ((ncols + 63) / 64) >= 448) cfg = 1;
+    if (cfg == 2 && p.K >= 1024 && ((p.M + 127) / 128) * ((ncols + 63) / 64) >= 448) cfg = 1;
     return cfg;
 }
 
 void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
-    static int ns_cfg[3] = {0, 0, 0};           // tuning: MAA_DMA_NS="n" (all tiles) or "n0,n1,n2" (128x128, 128x64, 64x64)
-    static const bool ns_parsed = [] {
-        if (const char* e = std::getenv("MAA_DMA_NS")) {
-            const int k = std::sscanf(e, "%d,%d,%d", &ns_cfg[0], &ns_cfg[1], &ns_cfg[2]);
-            if (k == 1) ns_cfg[1] = ns_cfg[2] = ns_cfg[0];
-        }
-        return true;
-    }();
-    (void)ns_parsed;
-    const int ns_env = ns_cfg[cfg];
     const long long ncols = (long long)p.N * (p.geglu ? 2 : 1);
     // LDS stages: inside the UNet the weights of every layer come cold from HBM (each layer's weights are 3-4x an
     // XCD's L2 and the whole model streams through once per DDIM step), so the deeper copy queue wins there even
@@ -276,22 +265,22 @@ void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
     // Round 2: the long-K contractions moved to igemm_dma2.hip; on what is left to the 64x64 tile (K = 320 / 640 linears,
     // ten or twenty chunks) two stages -- five workgroups per CU instead of two -- win: in-pipeline (2,3,2) -2.3 % vs (2,3,4)
     // (profiles/r2_dma2_inpipe_probes.txt).
-    int ns = ns_env ? ns_env : (cfg == 2 ? 2 : cfg == 1 ? 3 : 2);
+    int ns = cfg == 2 ? 2 : cfg == 1 ? 3 : 2;
     // Round 4: a 64x64 launch that puts fewer than ~2.5 workgroups on a CU (the K = 640 linears of the 5 x 39 level: 490 tiles
     // of 20 chunks) has one 16 KB chunk in flight per workgroup and waits ~1 us for each -- latency-, not fill-bound; such
-    // launches take the deeper queue (MAA_DMA_NS_LOW, parsed with the context's tuning; 0 keeps two stages everywhere).
-    if (!ns_env && cfg == 2 && ctx.tune.dma_ns_low > 2) {
+    // launches take a deeper queue (three stages; MAA_DMA_NS_LOW overrides, 2 = as the others): one batch in flight 842.4 /
+    // 842.2 / 844.6 ms with two stages everywhere against 839.1 (four) / 838.8 (three) in the same call
+    // (profiles/r4_rowchain_ab_v1_serial_loop.txt).
+    if (cfg == 2 && ctx.tune.dma_ns_low > 2) {
         const long long tiles = (long long)((p.M + 63) / 64) * ((ncols + 63) / 64);
         if (tiles * 2 < 5LL * device_cu_count(ctx.device)) ns = ctx.tune.dma_ns_low;
     }
     switch (cfg) {
         case 0:
-            if (ns >= 3) launch_one<128, 128, 2, 2, 3>(ctx, p, Nb);
-            else launch_one<128, 128, 2, 2, 2>(ctx, p, Nb);
+            launch_one<128, 128, 2, 2, 2>(ctx, p, Nb);
             break;
         case 1:
-            if (ns >= 3) launch_one<128, 64, 2, 2, 3>(ctx, p, Nb);
-            else launch_one<128, 64, 2, 2, 2>(ctx, p, Nb);
+            launch_one<128, 64, 2, 2, 3>(ctx, p, Nb);
             break;
         default:
             if (ns >= 4) launch_one<64, 64, 2, 2, 4>(ctx, p, Nb);

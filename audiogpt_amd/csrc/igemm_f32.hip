@@ -401,8 +401,7 @@ inline double tile_cost(long long M, long long N, int Z, int BM, int BN, double 
 void launch_igemm(const Ctx& ctx, const IGemm& p_in) {
     IGemm p = p_in;
     p.zeros = ctx.zeros;
-    static const int no_pair = std::getenv("MAA_NO_PAIR_STORE") ? 1 : 0;
-    p.no_pair = no_pair;
+    p.no_pair = 0;
     MAA_CHECK(p.zeros != nullptr, "context has no zero page");
     // precision mode of the context: 1 = bf16x3 split, 2 = plain bf16 operands; problems the bf16 engine cannot
     // take (B not k-contiguous, odd channel counts) run on the exact-fp32 kernel below.  (launch_igemm_bf16 also runs

@@ -111,8 +111,8 @@ struct StepGraph {
     StepGraph& operator=(const StepGraph&) = delete;
 };
 
-// Tuning / test knobs that used to be read from the environment on every launch: parsed once when a context is created
-// (and again by maa_ctx_reload_tuning, which the tests call after changing the environment).
+// Test / A-B switches: every one of them is parsed in Tuning::load (runtime.cpp) -- the only place the library reads the
+// environment -- when a context is created and again by maa_ctx_reload_tuning; a kept DDIM graph is dropped on reload.
 struct Tuning {
     std::string dma2;                       // MAA_DMA2 = "off" | "ns,pipe,S[,kmin[,kmax]]"
     std::map<int, std::string> dma2_n;      // MAA_DMA2_N<packed N>
@@ -120,7 +120,10 @@ struct Tuning {
     std::string pp, pp1;                    // MAA_PP / MAA_PP1 = "off" | "bn,S"
     int pp_dbg = -1;                        // MAA_PP_DBG: ablation mask of igemm_pp's TUNE instantiation (-1: product kernel)
     bool op_presplit = false;               // MAA_OP_PRESPLIT=1: the maa_op_* test entry points hand activations over as split32
-    int dma_ns_low = 0;                     // MAA_DMA_NS_LOW: LDS stages of a 64x64 LDS-DMA launch with < 2.5 workgroups per CU (0: as the others)
+    int dma_ns_low = 3;                     // MAA_DMA_NS_LOW: LDS stages of a 64x64 LDS-DMA launch with < 2.5 workgroups per CU (2: as the others)
+    bool no_dma = false;                    // MAA_NO_DMA: every bf16 contraction on the register-staged engine (bit-identity tests)
+    bool no_halo = false;                   // MAA_NO_HALO: the narrow vocoder stages through the implicit GEMM (bit-identity test)
+    bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
     bool rowchain = true;                   // MAA_ROWCHAIN=0: the transformer's short-K linears stay separate launches (A/B, tests)
     void load();
 };

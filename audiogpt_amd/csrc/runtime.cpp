@@ -115,17 +115,10 @@ namespace {
 struct TileKnobs {
     double eff[3] = {1.00, 0.92, 0.80};       // per-block efficiency of 128x128 / 128x64 / 64x64
     double conc[3] = {0.55, 0.85, 1.00};      // latency hiding with 1 / 2 / >=3 co-resident blocks per CU
-    int force = -1;
-    TileKnobs() {
-        if (const char* e = std::getenv("MAA_TILE_EFF")) std::sscanf(e, "%lf,%lf,%lf", &eff[0], &eff[1], &eff[2]);
-        if (const char* e = std::getenv("MAA_CONC_EFF")) std::sscanf(e, "%lf,%lf,%lf", &conc[0], &conc[1], &conc[2]);
-        if (const char* e = std::getenv("MAA_FORCE_CFG")) force = std::atoi(e);
-    }
 };
 }  // namespace
 int choose_tile(long long M, long long N, int Z, bool bf16) {
     static const TileKnobs k;
-    if (k.force >= 0 && k.force <= 2) return k.force;
     static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
     const int max_occ[3] = {bf16 ? 2 : 3, bf16 ? 2 : 4, 4};   // blocks per CU allowed by LDS / registers
     int best = 0;
@@ -151,7 +144,13 @@ const HostTensor& get(const StateDict& sd, const std::string& name) {
 }
 bool has(const StateDict& sd, const std::string& name) { return sd.find(name) != sd.end(); }
 
+// The ONE place the library reads its environment: when a context is created and in maa_ctx_reload_tuning.  Every knob is a
+// test / A-B switch with the product's behaviour as its default; -DMAA_NO_TUNING compiles the parsing out (a deployment build
+// whose behaviour cannot be changed from outside).
 void Tuning::load() {
+#ifdef MAA_NO_TUNING
+    return;
+#endif
     auto get_s = [](const char* name) {
         const char* e = std::getenv(name);
         return std::string(e ? e : "");
@@ -171,7 +170,10 @@ void Tuning::load() {
     const std::string ps = get_s("MAA_OP_PRESPLIT");
     op_presplit = !ps.empty() && ps[0] == '1';
     const std::string nl = get_s("MAA_DMA_NS_LOW");
-    dma_ns_low = nl.empty() ? 0 : std::atoi(nl.c_str());
+    dma_ns_low = nl.empty() ? 3 : std::atoi(nl.c_str());
+    no_dma = !get_s("MAA_NO_DMA").empty();
+    no_halo = !get_s("MAA_NO_HALO").empty();
+    snake_untiled = !get_s("MAA_SNAKE_UNTILED").empty();
     const std::string rc = get_s("MAA_ROWCHAIN");
     rowchain = rc.empty() || rc[0] != '0';
 }

@@ -406,7 +406,7 @@ struct UNet::Impl {
         const float scale = 1.0f / std::sqrt((float)s.dh);
         // attention outputs and the GEGLU product feed exactly one projection each: in the bf16 modes they are written
         // as split32 rows, so to_out / ff.net.2 take the LDS-DMA engine with no per-tile conversion
-        static const bool no_osplit = std::getenv("MAA_NO_OSPLIT") != nullptr;      // A/B timing only
+        const bool no_osplit = false;
         const int o_sp = !no_osplit && sp && flash_attention_covers(ctx, s.dh) ? 1 : 0;
         const int g_sp = !no_osplit && split_for_gemm(ctx, 4 * inner) ? 1 : 0;
         int y_sp = 0;

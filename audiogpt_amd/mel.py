@@ -38,6 +38,9 @@ N_MELS = 80
 FMIN, FMAX = 125.0, 7600.0
 MEL_LEN = 848
 PAD_MODE = os.environ.get("AUDIOGPT_AMD_STFT_PAD", "reflect")      # librosa <= 0.9.2 (the reference's); "constant" = librosa >= 0.10
+if PAD_MODE not in ("reflect", "constant"):
+    raise ValueError("AUDIOGPT_AMD_STFT_PAD must be 'reflect' (librosa <= 0.9.2, the default) or 'constant' (librosa >= 0.10), got %r"
+                     % PAD_MODE)
 
 
 def hz_to_mel(f):

@@ -86,6 +86,12 @@ class T2A:
             scores = [float(self.scorer(prompt, wav, sr)) for sr, wav in wav_list]
             return wav_list[int(np.argmax(scores))]
         if self.clap_model is None:
+            if not getattr(T2A, "_warned_no_scorer", False):
+                T2A._warned_no_scorer = True
+                import warnings
+                warnings.warn("T2A.select_best_audio: no CLAP scorer configured (clap= / scorer= / clap_model.* in the checkpoint): "
+                              "returning the first of the n samples instead of the best one (the reference always loads "
+                              "CLAP_weights_2022.pth, audio-chatgpt.py:146)")
             return wav_list[0]
         clap_model = self.clap_model                                                  # audio-chatgpt.py:186-199
         text_embeddings = clap_model.get_text_embeddings([prompt])

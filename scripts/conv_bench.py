@@ -27,10 +27,10 @@ for i, s in enumerate(SHAPES):
     print("  [%d] %s" % (i, s[0]))
 combos = [{}]
 if mode == "sweep":
-    combos += [{"MAA_NO_DMA": "1"}] + [{"MAA_FORCE_CFG": str(c), "MAA_DMA_NS": str(ns)} for c, nss in ((0, (2, 3)), (1, (2, 3)), (2, (2, 3, 4))) for ns in nss]
+    combos += [{"MAA_NO_DMA": "1"}] + [{"MAA_DMA_NS_LOW": str(ns)} for ns in (2, 3, 4)]      # (MAA_FORCE_CFG / MAA_DMA_NS were retired in round 4)
 for env in combos:
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, __file__, prec, "child"], env=e, capture_output=True, text=True)
-    tag = ("regs" if "MAA_NO_DMA" in env else "cfg%s NS%s" % (env.get("MAA_FORCE_CFG", "-"), env.get("MAA_DMA_NS", "-"))) if env else "default "
+    tag = ("regs" if "MAA_NO_DMA" in env else "NS_LOW%s" % env.get("MAA_DMA_NS_LOW", "-")) if env else "default "
     print("%-10s %s" % (tag, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else "FAILED " + r.stderr[-300:]), flush=True)

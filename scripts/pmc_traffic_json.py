@@ -2,6 +2,10 @@
 scripts/gpu_profile.sh, stamped with what they were measured on so that bench.py can refuse stale numbers.
 
     python scripts/pmc_traffic_json.py <prof_pmc.txt> <precision> <ddim steps of the PMC workload> <out.json>
+    python scripts/pmc_traffic_json.py <prof_pmc.txt> <precision> <units of the PMC workload> <out.json> --section hifigan64|mixed
+
+With --section the table is merged into <out.json> under "secondary"[section] (bench.py's secondary workloads look their
+dominant kernel up there); a unit is one generator pass (hifigan64) or one DDIM step of each tool (mixed).
 
 FETCH_SIZE / WRITE_SIZE are in KB (rocprofv3 derived counters); on gfx950 FETCH_SIZE counts each 128-byte request as 64
 bytes, so it is doubled (MI355X_MICROARCH.md, HBM section).  The two counters come from separate passes.  A bench label
@@ -14,6 +18,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 path, prec, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+section_name = sys.argv[sys.argv.index("--section") + 1] if "--section" in sys.argv else None
 LABELS = {  # bench.py / maa_prof label -> (rocprof kernel prefixes, prefix whose launch count is the label's)
     "igemm_dma_bf16x3<64x64>": (["igemm_dma_kernel<64, 64"], "igemm_dma_kernel<64, 64"),
     "igemm_dma_bf16x3<128x64>": (["igemm_dma_kernel<128, 64"], "igemm_dma_kernel<128, 64"),
@@ -25,6 +30,12 @@ LABELS = {  # bench.py / maa_prof label -> (rocprof kernel prefixes, prefix whos
     "igemm_pp_bf16x3<256x128>": (["igemm_pp_kernel<2, 2, 2, 2"], "igemm_pp_kernel<2, 2, 2, 2"),
     "igemm_pp_bf16x3<256x160>": (["igemm_pp_kernel<1, 5, 4, 1"], "igemm_pp_kernel<1, 5, 4, 1"),
     "igemm_pp1_bf16x3<256x128>": (["igemm_pp1_kernel<2, 2, 2, 2"], "igemm_pp1_kernel<2, 2, 2, 2"),
+    "igemm_rowchain_bf16x3<64x320>": (["rowchain_kernel<5, 3"], "rowchain_kernel<5, 3"),
+    "igemm_rowchain_bf16x3<64x256>": (["rowchain_kernel<4, 3"], "rowchain_kernel<4, 3"),
+    "igemm_bf16x3<128x128>": (["igemm_bf16_kernel<128, 128, 2, 2, 3"], "igemm_bf16_kernel<128, 128, 2, 2, 3"),
+    "igemm_bf16x3<128x64>": (["igemm_bf16_kernel<128, 64, 2, 2, 3"], "igemm_bf16_kernel<128, 64, 2, 2, 3"),
+    "igemm_bf16x3<64x64>": (["igemm_bf16_kernel<64, 64, 2, 2, 3"], "igemm_bf16_kernel<64, 64, 2, 2, 3"),
+    "igemm_bf16x3<256x32>": (["igemm_bf16_kernel<256, 32, 4, 1, 3"], "igemm_bf16_kernel<256, 32, 4, 1, 3"),
     "igemm_f32<64x64>": (["igemm_f32_kernel<64, 64"], "igemm_f32_kernel<64, 64"),
     "igemm_f32<128x64>": (["igemm_f32_kernel<128, 64"], "igemm_f32_kernel<128, 64"),
     "igemm_f32<128x128>": (["igemm_f32_kernel<128, 128"], "igemm_f32_kernel<128, 128"),
@@ -63,12 +74,27 @@ for label, (prefixes, count_prefix) in LABELS.items():
         if busy and act:
             kernels[label]["mfma_busy"] = busy / (act / 8.0 * 1024.0)
 from audiogpt_amd.build import _source_hash  # noqa: E402
-json.dump({"precision": prec, "source_hash": _source_hash(), "ddim_steps": steps, "kernels": kernels,
-           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate kernel-trace passes over %d eager DDIM steps of the "
-                   "benchmark batch (8 latents + CFG); HBM-side bytes = 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B, "
-                   "MI355X_MICROARCH.md) + WRITE_SIZE, per launch of the labelled contraction (a split-K contraction includes "
-                   "its reduce launch); Infinity-Cache hits are counted by these counters; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) "
-                   "of the GEMM launch, from a third pass; source %s" % (steps, path)},
-          open(out, "w"), indent=1)
+NOTE = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate kernel-trace passes over %s; HBM-side bytes = 2 x FETCH_SIZE (gfx950 "
+        "counts 128-B requests as 64 B, MI355X_MICROARCH.md) + WRITE_SIZE, per launch of the labelled contraction (a split-K "
+        "contraction includes its reduce launch); Infinity-Cache hits are counted by these counters; mfma_busy = "
+        "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) of the GEMM launch, from a third pass; source %s")
+if section_name is None:
+    doc = {"precision": prec, "source_hash": _source_hash(), "ddim_steps": steps, "kernels": kernels,
+           "note": NOTE % ("%d eager DDIM steps of the benchmark batch (8 latents + CFG)" % steps, path)}
+    if os.path.exists(out):          # keep the secondary workloads' tables of an earlier call on the same sources
+        try:
+            old = json.load(open(out))
+            if old.get("source_hash") == doc["source_hash"] and old.get("precision") == prec and "secondary" in old:
+                doc["secondary"] = old["secondary"]
+        except Exception:
+            pass
+else:
+    doc = json.load(open(out)) if os.path.exists(out) else {"precision": prec, "source_hash": _source_hash(), "kernels": {}}
+    for v in kernels.values():
+        v["launches_per_unit"] = v.pop("launches_per_ddim_step")
+    doc.setdefault("secondary", {})[section_name] = {
+        "precision": prec, "source_hash": _source_hash(), "units": steps, "kernels": kernels,
+        "note": NOTE % ("%d unit(s) of `bench.py --workload %s` (a unit = one generator pass / one DDIM step of each tool)" % (steps, section_name), path)}
+json.dump(doc, open(out, "w"), indent=1)
 for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["launches"]):
-    print("%-40s %8.1f MB per launch  (%d launches, %.1f per DDIM step)" % (k, v["hbm_bytes_per_launch"] / 1e6, v["launches"], v["launches_per_ddim_step"]))
+    print("%-40s %8.1f MB per launch  (%d launches, %.1f per unit)" % (k, v["hbm_bytes_per_launch"] / 1e6, v["launches"], v.get("launches_per_ddim_step", v.get("launches_per_unit", 0))))

@@ -47,7 +47,7 @@ def test_clap_score_matches_reference(golden, precision):
     from audiogpt_amd.clap import CLAPWrapper
     g = golden("clap_score")
     cfg = C.CLAP_SCORER
-    clap = CLAPWrapper(device="cuda:0", precision=precision)           # seeded weights (21 / 22), as the golden
+    clap = CLAPWrapper(device="cuda:0", precision=precision, synthetic=True)      # seeded weights (21 / 22), as the golden
     te = clap.get_text_embeddings_from_ids([g["input_ids"]])
     check(f"{precision}_clap_score_text_vs_reference", te, g["text_embedding"], 1e-4)
     ae = clap.audio_encoder.embed(_score_logmel(g, cfg))
@@ -122,7 +122,7 @@ def test_clap_wrapper_scores_waveforms_like_the_oracle_chain():
     from audiogpt_amd.clap import CLAPWrapper
     from oracle import clap_audio as O
     cfg = C.CLAP_SCORER
-    clap = CLAPWrapper(device="cuda:0", precision="bf16x3", crop_start=12345)
+    clap = CLAPWrapper(device="cuda:0", precision="bf16x3", crop_start=12345, synthetic=True)
     tsd = WT.make_clap_text_state_dict(cfg["text"], seed=21)
     asd = WT.make_clap_audio_state_dict(cfg["audio"], seed=22)
     rs = np.random.RandomState(5)
@@ -159,7 +159,7 @@ def test_T2A_select_best_audio_uses_the_device_scorer():
             return [101, 2023, 2003, 1037, 3231, 102]
     t2a = T2A.__new__(T2A)                     # select_best_audio only needs the scorer fields
     t2a.scorer = None
-    t2a.clap_model = CLAPWrapper(device="cuda:0", precision="bf16x3", tokenizer=Tok(), crop_start=777)
+    t2a.clap_model = CLAPWrapper(device="cuda:0", precision="bf16x3", tokenizer=Tok(), crop_start=777, synthetic=True)
     rs = np.random.RandomState(7)
     n = 159744
     t = np.arange(n) / 16000.0
