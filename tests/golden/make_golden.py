@@ -954,6 +954,11 @@ def main():
     bigvgan_case("bigvgan_16k_t624", C.BIGVGAN_16K, 624, {})
     config3_case("hifigan_ns512_cfg3_row63", C.HIFIGAN_NS_512, 63)
     config3_case("hifigan_ns128_cfg3_row0", C.HIFIGAN_NS_128, 0)
+    try:          # records that are not state_dict layouts ("_third_party_pins") survive a full regeneration
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest.update({k: v for k, v in json.load(f).items() if k.startswith("_")})
+    except (OSError, ValueError):
+        pass
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     print("torch", torch.__version__)

@@ -340,6 +340,42 @@ def test_scorer_front_end_tables():
     assert np.abs(out[2000:42000] - want[2000:42000]).max() < 5e-3
 
 
+def test_resampler_matches_an_independent_polyphase_implementation():
+    """torchaudio is absent, so its default resampler (CLAPWrapper.py:103-110: T.Resample(16000 -> 44100), sinc interpolation with a
+    Hann window, lowpass_filter_width 6, rolloff 0.99) cannot be run here.  Its restatements -- the oracle's strided convolution
+    and the kernel bank the device contraction uses -- are pinned to an INDEPENDENT second implementation instead: scipy's polyphase
+    engine (resample_poly / upfirdn) given the same documented prototype FIR sampled on the 1 / (orig * new) grid.  Zero padding at
+    both ends and the output length ceil(new n / orig) are the same in both (tests/golden/manifest.json, _third_party_pins)."""
+    import math
+
+    import numpy as np
+    import torch
+    from scipy.signal import resample_poly
+
+    from audiogpt_amd.clap import sinc_resample_kernel
+    from oracle import clap_audio as O
+    for orig_f, new_f, n in ((16000, 44100, 5000), (22050, 44100, 3001), (48000, 44100, 4097)):
+        lpw, rolloff = 6, 0.99
+        g = math.gcd(orig_f, new_f)
+        orig, new = orig_f // g, new_f // g
+        base = min(orig, new) * rolloff
+        half = int(math.ceil(lpw * orig * new / base))
+        t = np.clip(np.arange(-half, half + 1, dtype=np.float64) * base / (orig * new), -lpw, lpw)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            proto = np.where(t == 0, 1.0, np.sin(np.pi * t) / (np.pi * t)) * np.cos(t * np.pi / lpw / 2) ** 2 * (base / orig)
+        x = np.random.RandomState(n).randn(2, n)
+        want = resample_poly(x, new, orig, axis=-1, window=proto / new)          # (scipy multiplies its taps by `up`)
+        got = O.resample(torch.from_numpy(x).float(), orig_f, new_f).numpy()
+        assert got.shape == want.shape == (2, math.ceil(new * n / orig))
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max(), (orig_f, np.abs(got - want).max())
+        # the device path's kernel bank, applied as the strided contraction the library runs
+        k, width = sinc_resample_kernel(orig_f, new_f)
+        xp = np.pad(x[0].astype(np.float32), (width, width + orig))
+        frames = np.lib.stride_tricks.sliding_window_view(xp, k.shape[1])[::orig]
+        dev = (frames.astype(np.float64) @ k.T.astype(np.float64)).reshape(-1)[:want.shape[1]]
+        assert np.abs(dev - want[0]).max() <= 2e-6 * np.abs(want).max()
+
+
 def test_product_tree_never_touches_the_oracle_or_the_reference_tree():
     """The oracle is test infrastructure: nothing under audiogpt_amd/ (or include/) may import or name it, and nothing
     that runs on the GPU box (product, bench.py, __graft_entry__.py, tests other than the golden generator) may read
