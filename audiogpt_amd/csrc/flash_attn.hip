@@ -80,6 +80,7 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
     const int lq = lane & 31, lh = lane >> 5;
     const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
     const int q0 = blockIdx.x * 128 + wid * 32;
+    const bool wave_live = q0 < a.Nq;          // wave-uniform
     const float* qp = a.q + b * a.q_bs + h * a.hsq;
     const float* kp = a.k + b * a.k_bs + h * a.hsk;
     const float* vp = a.v + b * a.v_bs + h * a.hsv;
@@ -220,107 +221,109 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
         const unsigned short* base = smem + buf * BUF;
         const unsigned short* vt = base + PL * K_PLANE;
 
-        // ---- S^T = K_tile . Q^T
-        f32x16 sacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(base + lq * LDKK + ks * 16 + lh * 8);
-            if constexpr (TERMS == 3) {
-                const bf16x8 kl = *reinterpret_cast<const bf16x8*>(base + K_PLANE + lq * LDKK + ks * 16 + lh * 8);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, as_bf16x8(qh[ks]), sacc, 0, 0, 0);
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, as_bf16x8(ql[ks]), sacc, 0, 0, 0);
-            }
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, as_bf16x8(qh[ks]), sacc, 0, 0, 0);
-        }
-
-        // ---- online softmax for query lq: this lane's keys are kt*32 + (r&3) + 8*(r>>2) + 4*lh.  The scores are already
-        // scaled (natural-log units on the precise path, log2 units on the exp2 path); only a short last tile or a causal
-        // mask needs the per-key test (uniform branch)
-        float p[16];
-        float mt = -INFINITY;
-        if (!a.causal && (kt + 1) * KT <= a.Nk) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = sacc[r];
-                mt = fmaxf(mt, p[r]);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * KT + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                p[r] = (key < a.Nk && (!a.causal || key <= q0 + lq)) ? sacc[r] : -INFINITY;
-                mt = fmaxf(mt, p[r]);
-            }
-        }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        // exp through v_exp_f32 (~1 ulp): the softmax is the VALU-heavy part of this kernel; the running maximum settles
-        // after the first tiles, so the rescale of O is skipped for a wave whose lanes all kept their maximum (alpha == 1
-        // exactly)
-        float alpha, ls = 0.f;
-        if (a.precise_exp) {
-            alpha = expf(m_run - m_new);                  // first tile: exp(-inf) = 0
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = expf(p[r] - m_new);                // masked keys: exp(-inf) = 0
-                ls += p[r];
-            }
-        } else {
-            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(p[r] - m_new);
-                ls += p[r];
-            }
-        }
-        ls += __shfl_xor(ls, 32, 64);
-        l_run = l_run * alpha + ls;
-        const bool moved = m_new != m_run;
-        m_run = m_new;
-        if (__any(moved)) {
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[mb][r] *= alpha;
-        }
-
-        // ---- O^T += V^T . P^T ; k-slot (lh*8 + t) of step u  <->  key 16u + 4 lh + (t&3) + 8 (t>>2)  <->  p[8u + t]
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            Frag ph, pl;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if constexpr (TERMS == 1)
-                    ph.w[t] = pk_bf16(p[8 * u + 2 * t], p[8 * u + 2 * t + 1]);
-                else
-                    split2(p[8 * u + 2 * t], p[8 * u + 2 * t + 1], ph.w[t], pl.w[t]);
-            }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const unsigned short* vrow = vt + (mb * 32 + lq) * LDV + 16 * u + 4 * lh;
-                Frag vh, vl;
-                const uint2 a0 = *reinterpret_cast<const uint2*>(vrow);
-                const uint2 a1 = *reinterpret_cast<const uint2*>(vrow + 8);
-                vh.w[0] = a0.x;
-                vh.w[1] = a0.y;
-                vh.w[2] = a1.x;
-                vh.w[3] = a1.y;
+        if (wave_live) {      // a wave whose 32 query rows all lie past Nq (the 780 = 6 x 128 + 12 tail) only helps stage K / V
+            // ---- S^T = K_tile . Q^T
+            f32x16 sacc;
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    #pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kh = *reinterpret_cast<const bf16x8*>(base + lq * LDKK + ks * 16 + lh * 8);
                 if constexpr (TERMS == 3) {
-                    const uint2 c0 = *reinterpret_cast<const uint2*>(vrow + V_PLANE);
-                    const uint2 c1 = *reinterpret_cast<const uint2*>(vrow + V_PLANE + 8);
-                    vl.w[0] = c0.x;
-                    vl.w[1] = c0.y;
-                    vl.w[2] = c1.x;
-                    vl.w[3] = c1.y;
-                    oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vl), as_bf16x8(ph), oacc[mb], 0, 0, 0);
-                    oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vh), as_bf16x8(pl), oacc[mb], 0, 0, 0);
+                    const bf16x8 kl = *reinterpret_cast<const bf16x8*>(base + K_PLANE + lq * LDKK + ks * 16 + lh * 8);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, as_bf16x8(qh[ks]), sacc, 0, 0, 0);
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, as_bf16x8(ql[ks]), sacc, 0, 0, 0);
                 }
-                oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vh), as_bf16x8(ph), oacc[mb], 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, as_bf16x8(qh[ks]), sacc, 0, 0, 0);
             }
-        }
 
+            // ---- online softmax for query lq: this lane's keys are kt*32 + (r&3) + 8*(r>>2) + 4*lh.  The scores are already
+            // scaled (natural-log units on the precise path, log2 units on the exp2 path); only a short last tile or a causal
+            // mask needs the per-key test (uniform branch)
+            float p[16];
+            float mt = -INFINITY;
+            if (!a.causal && (kt + 1) * KT <= a.Nk) {
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[r] = sacc[r];
+                    mt = fmaxf(mt, p[r]);
+                }
+            } else {
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * KT + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    p[r] = (key < a.Nk && (!a.causal || key <= q0 + lq)) ? sacc[r] : -INFINITY;
+                    mt = fmaxf(mt, p[r]);
+                }
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m_run, mt);
+            // exp through v_exp_f32 (~1 ulp): the softmax is the VALU-heavy part of this kernel; the running maximum settles
+            // after the first tiles, so the rescale of O is skipped for a wave whose lanes all kept their maximum (alpha == 1
+            // exactly)
+            float alpha, ls = 0.f;
+            if (a.precise_exp) {
+                alpha = expf(m_run - m_new);                  // first tile: exp(-inf) = 0
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[r] = expf(p[r] - m_new);                // masked keys: exp(-inf) = 0
+                    ls += p[r];
+                }
+            } else {
+                alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[r] = __builtin_amdgcn_exp2f(p[r] - m_new);
+                    ls += p[r];
+                }
+            }
+            ls += __shfl_xor(ls, 32, 64);
+            l_run = l_run * alpha + ls;
+            const bool moved = m_new != m_run;
+            m_run = m_new;
+            if (__any(moved)) {
+    #pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[mb][r] *= alpha;
+            }
+
+            // ---- O^T += V^T . P^T ; k-slot (lh*8 + t) of step u  <->  key 16u + 4 lh + (t&3) + 8 (t>>2)  <->  p[8u + t]
+    #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                Frag ph, pl;
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if constexpr (TERMS == 1)
+                        ph.w[t] = pk_bf16(p[8 * u + 2 * t], p[8 * u + 2 * t + 1]);
+                    else
+                        split2(p[8 * u + 2 * t], p[8 * u + 2 * t + 1], ph.w[t], pl.w[t]);
+                }
+    #pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const unsigned short* vrow = vt + (mb * 32 + lq) * LDV + 16 * u + 4 * lh;
+                    Frag vh, vl;
+                    const uint2 a0 = *reinterpret_cast<const uint2*>(vrow);
+                    const uint2 a1 = *reinterpret_cast<const uint2*>(vrow + 8);
+                    vh.w[0] = a0.x;
+                    vh.w[1] = a0.y;
+                    vh.w[2] = a1.x;
+                    vh.w[3] = a1.y;
+                    if constexpr (TERMS == 3) {
+                        const uint2 c0 = *reinterpret_cast<const uint2*>(vrow + V_PLANE);
+                        const uint2 c1 = *reinterpret_cast<const uint2*>(vrow + V_PLANE + 8);
+                        vl.w[0] = c0.x;
+                        vl.w[1] = c0.y;
+                        vl.w[2] = c1.x;
+                        vl.w[3] = c1.y;
+                        oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vl), as_bf16x8(ph), oacc[mb], 0, 0, 0);
+                        oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vh), as_bf16x8(pl), oacc[mb], 0, 0, 0);
+                    }
+                    oacc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(vh), as_bf16x8(ph), oacc[mb], 0, 0, 0);
+                }
+            }
+
+        }
         store_tile(buf ^ 1);
         __syncthreads();
     }

@@ -236,7 +236,8 @@ void launch_igemm_pp1(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, 
 // consumer instead of fp32 (same byte size).  Takes 2*B*C floats of scratch (per-sample channel scale/shift) from the arena.
 void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int B, int HW,
                       int groups, const float* gamma, const float* beta, float eps, int silu, float* out,
-                      int out_split = 0);
+                      int out_split = 0, float* raw_split = nullptr);
+// raw_split: optional second output [B, HW, C1+C2] -- the UN-normalised (x1 | x2) rows as split32 lines (C % 32 == 0)
 void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, const float* gamma, const float* beta,
                       float eps, float* out, int out_split = 0);
 // fp32 [rows, C] -> split32 rows of the same pitch (C % 32 == 0): tests and micro-benchmarks of the engines that take

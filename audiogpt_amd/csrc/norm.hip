@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x1, int ld1, int C1,
                                                        const float* __restrict__ x2, int ld2, int C2, int HW,
                                                        const float* __restrict__ tab, int silu,
-                                                       float* __restrict__ out, int split) {
+                                                       float* __restrict__ out, int split, float* __restrict__ raw_split) {
     const int C = C1 + C2, c4n = C >> 2;
     const int b = blockIdx.y, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int r0 = blockIdx.x * 16 + ty;
@@ -153,6 +153,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             y.w = __fdividef(y.w, 1.f + __expf(-y.w));
         }
         store4(out, row, c, C, split, y);
+        // second output: the UN-normalised row as split32 (the ResBlock's 1x1 skip convolution reads the same (h | skip) rows:
+        // with this copy both of its operands reach LDS by DMA instead of through the register-staged engine)
+        if (raw_split) store4(raw_split, row, c, C, 1, v);
     }
 }
 
@@ -307,7 +310,7 @@ void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, 
 
 void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int B, int HW,
                       int groups, const float* gamma, const float* beta, float eps, int silu, float* out,
-                      int out_split) {
+                      int out_split, float* raw_split) {
     const int C = C1 + C2;
     float* tab = ctx.ws.alloc_f((size_t)2 * B * C);    // per-(sample, channel) {scale, shift}; released with the caller's arena mark
     if (ctx.ws.dry) return;
@@ -320,7 +323,7 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
     int nz = (768 + rb * B - 1) / (rb * B);         // aim at >= 3 workgroups per CU
     nz = nz < 1 ? 1 : nz > passes ? passes : nz;
     hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)rb, (unsigned)B, (unsigned)nz), dim3(256), 0, ctx.stream, x1, ld1,
-                       C1, x2, ld2, C2, HW, tab, silu, out, out_split);
+                       C1, x2, ld2, C2, HW, tab, silu, out, out_split, raw_split);
     MAA_HIP(hipGetLastError());
 }
 

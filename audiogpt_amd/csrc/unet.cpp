@@ -258,8 +258,16 @@ struct UNet::Impl {
         const size_t mk = ctx.ws.mark();
         T4 t1 = alloc_t(ctx, B, H, W, r.cin);
         t1.split = r.updown != 1 && split_for_gemm(ctx, r.cin);     // (the avg-pool of a down block reads fp32)
+        // a ResBlock that changes the channel count runs a 1x1 skip convolution over the same (h | skip) rows GroupNorm reads:
+        // the apply pass also writes them as split32, so that contraction takes the LDS-DMA engine (both operands by DMA; same
+        // products in the same order as the register-staged engine it used to run on -- bit-identical)
+        T4 xraw;
+        if (r.has_skip && r.updown == 0 && split_for_gemm(ctx, r.cin) && r.skip.split) {
+            xraw = alloc_t(ctx, B, H, W, r.cin);
+            xraw.split = true;
+        }
         launch_groupnorm(ctx, x1.p, x1.C, x1.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x2 ? x2->C : 0, B, H * W, 32,
-                         r.g1, r.b1, 1e-5f, 1, t1.p, t1.split);
+                         r.g1, r.b1, 1e-5f, 1, t1.p, t1.split, xraw.p);
         T4 h1 = alloc_t(ctx, B, Ho, Wo, r.cout);
         ConvOpt o1;
         o1.KH = o1.KW = 3;
@@ -292,7 +300,10 @@ struct UNet::Impl {
             MAA_CHECK(r.updown == 0, "skip conv with up/down");
             T4 sk = alloc_t(ctx, B, H, W, r.cout);
             ConvOpt os;
-            conv_into(ctx, x1, x2, r.skip, os, sk);
+            if (xraw.p)
+                conv_into(ctx, xraw, nullptr, r.skip, os, sk);
+            else
+                conv_into(ctx, x1, x2, r.skip, os, sk);
             resid = sk.p;
         } else {
             MAA_CHECK(!x2, "identity skip needs a single source");

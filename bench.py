@@ -588,8 +588,11 @@ def run_tool_latency(dev, precision, cpu_parts=None, cpu_base=True, roofline=Tru
                      (audio-chatgpt.py:158-199)
       I2A.img2audio  n = 1, CFG 3 over a 1-token context, VAE, BigVGAN (audio-chatgpt.py:232-261)
     single stream, hipGraph-captured DDIM steps; seeded random-init weights (CLAP included), synthetic conditioning encoders."""
+    import contextlib
+
     from audiogpt_amd.clap import CLAPWrapper
     from audiogpt_amd.tools import I2A, T2A
+    quiet = lambda: contextlib.redirect_stdout(sys.stderr)      # noqa: E731  (the tools print like the reference's; stdout is the JSON line's)
 
     class Tok:          # the host-side tokenizer is a constructor argument (its vocabulary file does not ship): fixed ids
         def __call__(self, text):
@@ -597,10 +600,11 @@ def run_tool_latency(dev, precision, cpu_parts=None, cpu_base=True, roofline=Tru
     out = {"metric": "tool latency, call to waveform (ms)", "unit": "ms", "higher_is_better": False, "dtype": precision, "n_gpus": 1,
            "data": "seeded random-init weights (UNet, VAE, BigVGAN, CLAP); synthetic text / image embeddings",
            "config": {"workload": "T2A.txt2audio(n_samples=3, scale=1.5, ddim_steps=100) + CLAP best-of-3; I2A.img2audio(n=1, scale=3, ddim_steps=100)"}}
-    t2a = T2A(dev, precision=precision)
+    with quiet():
+        t2a = T2A(dev, precision=precision)
     t2a.clap_model = CLAPWrapper(ctx=t2a.sampler.model.ctx, tokenizer=Tok(), crop_start=0, synthetic=True)
     text = "a dog barks while rain falls on a tin roof"
-    with torch.no_grad():
+    with torch.no_grad(), quiet():
         t2a.txt2audio(text)                                   # first call: workspace + graph capture
         ms_t2a, (sr, wav) = _timed(lambda: t2a.txt2audio(text), 2)
     clip_s = wav.shape[0] / float(sr)
@@ -608,14 +612,15 @@ def run_tool_latency(dev, precision, cpu_parts=None, cpu_base=True, roofline=Tru
                             "candidate_audio_seconds_per_sec": 3 * clip_s / ms_t2a}
     if roofline:
         t2a.sampler.model.ctx.prof_begin()
-        with torch.no_grad():
+        with torch.no_grad(), quiet():
             t2a.txt2audio(text)
         rows = t2a.sampler.model.ctx.prof_end()
         out["roofline"] = roofline_of(rows, precision)
         out["roofline"]["note"] = "T2A.txt2audio call, graph replay as shipped (kernels inside graph launches are not event-timed: this table covers the eager part -- VAE, BigVGAN, CLAP)"
     img = np.random.RandomState(3).rand(64, 64, 3).astype(np.float32)
-    i2a = I2A(dev, precision=precision)
-    with torch.no_grad():
+    with quiet():
+        i2a = I2A(dev, precision=precision)
+    with torch.no_grad(), quiet():
         i2a.img2audio(img)
         ms_i2a, (sr2, wav2) = _timed(lambda: i2a.img2audio(img), 2)
     out["I2A_img2audio"] = {"ms": 1e3 * ms_i2a, "clip_seconds": wav2.shape[0] / float(sr2), "realtime_factor": wav2.shape[0] / float(sr2) / ms_i2a}
