@@ -57,12 +57,18 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
     MAA_CHECK(!logging || n_logged == a.n_log, "ddim: n_log does not match log_every_t");
     auto up = [](size_t n) { return (n + 63) / 64 * 64; };      // floats, 256-byte aligned pieces
     const size_t n_cc = concat ? (size_t)a.B * (per_in - per) : 0;
+    // the ResBlocks' time-embedding rows of all S steps, computed once per call (every sample of a step shares t; the I2A variant
+    // adds the sample's context to the embedding and keeps the per-forward computation): six launches leave every step
+    const bool emb_hoist = !unet.config().add_context_to_emb;
+    const size_t emb_w = emb_hoist ? (size_t)unet.emb_width() : 0;
     const size_t o_tab = 0, o_step = o_tab + up(h_tab.size()), o_t = o_step + 64, o_coef = o_t + up(nB),
                  o_xin = o_coef + 64, o_eps = o_xin + up((size_t)nB * per_in), o_x = o_eps + up((size_t)nB * per),
-                 o_cc = o_x + up((size_t)a.B * per), total = o_cc + up(n_cc);
+                 o_cc = o_x + up((size_t)a.B * per), o_embt = o_cc + up(n_cc), o_emb = o_embt + up((size_t)a.S * emb_w),
+                 total = o_emb + up(emb_w);
     float* slab = static_cast<float*>(ctx.sampler_scratch.get(total * sizeof(float), ctx.stream));
     float *tab_t = slab + o_tab, *tab_coef = slab + o_tab + a.S, *cur_t = slab + o_t, *cur_coef = slab + o_coef,
-          *xin = slab + o_xin, *eps = slab + o_eps, *xs = slab + o_x, *ccs = slab + o_cc;
+          *xin = slab + o_xin, *eps = slab + o_eps, *xs = slab + o_x, *ccs = slab + o_cc, *emb_tab = slab + o_embt,
+          *cur_emb = slab + o_emb;
     // the trajectory runs on the slab's copy of the latent (and of the concat conditioning)
     MAA_HIP(hipMemcpyAsync(xs, d_x, (size_t)a.B * per * 4, hipMemcpyDeviceToDevice, ctx.stream));
     if (concat) MAA_HIP(hipMemcpyAsync(ccs, a.d_concat, n_cc * 4, hipMemcpyDeviceToDevice, ctx.stream));
@@ -70,6 +76,8 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
     const int h_step = a.S - 1;                        // ddim.py:143-145: flipped timesteps, index = total - i - 1
     MAA_HIP(hipMemcpyAsync(slab + o_tab, h_tab.data(), h_tab.size() * 4, hipMemcpyHostToDevice, ctx.stream));
     MAA_HIP(hipMemcpyAsync(d_step, &h_step, 4, hipMemcpyHostToDevice, ctx.stream));
+
+    if (emb_hoist) unet.emb_table(ctx, tab_t, a.S, emb_tab);      // (tab_t: the S timesteps as floats, uploaded above)
 
     // ---- conditioning: constant over the trajectory -> project K/V once
     if (!concat && a.d_cond) {
@@ -82,8 +90,8 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
     // one step: identical launches on identical addresses whatever the step (the index lives on the device)
     auto step_body = [&]() {
         launch_ddim_prepare(ctx, xs, concat ? ccs : nullptr, a.B, nB, per, per_in - per, tab_t, tab_coef, d_step, xin,
-                            cur_t, cur_coef, a.d_mask, a.d_x0, a.d_noise_q, a.S);
-        unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps);
+                            cur_t, cur_coef, a.d_mask, a.d_x0, a.d_noise_q, a.S, emb_hoist ? emb_tab : nullptr, (int)emb_w, cur_emb);
+        unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps, emb_hoist ? cur_emb : nullptr);
         launch_ddim_step(ctx, xin, per, per_in, eps, cfg ? eps + a.B * per : nullptr, a.scale, cur_coef, (long long)a.B * per, xs,
                          a.h_sigmas ? a.d_noise_p : nullptr, a.temperature, a.S, logging ? a.d_log_x : nullptr,
                          logging ? a.d_log_x0 : nullptr, d_step);

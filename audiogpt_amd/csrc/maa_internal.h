@@ -185,7 +185,7 @@ struct IGemm {
     float* c2 = nullptr;
     int ldc2 = 0;
     float c2_slope = 1.f;
-    int no_pair = 0;                 // MAA_NO_PAIR_STORE (A/B): plain 4-byte fp32 stores in the epilogue
+    int no_pair = 0;                 // (A/B, retired) plain 4-byte fp32 stores in the epilogue
     const float* zeros = nullptr;    // >= 16 B of zeros in device memory (filled in by launch_igemm)
     int m_fastest = 0;               // tile order inside an XCD's range: 1 = M-tiles fastest (MAA_TILE_ORDER=1: weights are
                                      // then fetched once chip-wide, but the conv's A re-reads lose their L2: +4 % step time)
@@ -272,7 +272,9 @@ void launch_ddim_update(const Ctx& ctx, const float* x, const float* eps_u, cons
 void launch_ddim_prepare(const Ctx& ctx, const float* x, const float* concat, int B, int nB, long long per,
                          long long per_c, const float* tab_t, const float* tab_coef, const int* step, float* xin,
                          float* cur_t, float* cur_coef, const float* mask = nullptr, const float* x0 = nullptr,
-                         const float* noise_q = nullptr, int S = 0);
+                         const float* noise_q = nullptr, int S = 0, const float* emb_tab = nullptr, int emb_w = 0,
+                         float* cur_emb = nullptr);
+// emb_tab [S][emb_w] / cur_emb [emb_w]: the step's precomputed ResBlock time-embedding row is copied into its fixed slot
 // the loop's update: x from the step's UNet input, optional sigma_t * noise * temperature, logged intermediates, index - 1
 void launch_ddim_step(const Ctx& ctx, const float* xin, long long per, long long per_in, const float* eps_u, const float* eps_c,
                       float scale, const float* coef, long long n, float* x_prev, const float* noise_p, float temperature, int S,

@@ -186,8 +186,10 @@ __global__ void ddim_prepare_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ tab_coef, const int* __restrict__ step,
                                     float* __restrict__ xin, float* __restrict__ cur_t, float* __restrict__ cur_coef,
                                     const float* __restrict__ mask, const float* __restrict__ x0, const float* __restrict__ noise_q,
-                                    int S) {
+                                    int S, const float* __restrict__ emb_tab, int emb_w, float* __restrict__ cur_emb) {
     const int idx = *step;
+    if (emb_tab)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < emb_w; i += gridDim.x * blockDim.x) cur_emb[i] = emb_tab[(long long)idx * emb_w + i];
     if (blockIdx.x == 0) {
         if (threadIdx.x < nB) cur_t[threadIdx.x] = tab_t[idx];
         if (threadIdx.x < 8) cur_coef[threadIdx.x] = tab_coef[idx * 8 + threadIdx.x];
@@ -385,10 +387,11 @@ void launch_ddim_update(const Ctx& ctx, const float* x, const float* eps_u, cons
 }
 void launch_ddim_prepare(const Ctx& ctx, const float* x, const float* concat, int B, int nB, long long per,
                          long long per_c, const float* tab_t, const float* tab_coef, const int* step, float* xin,
-                         float* cur_t, float* cur_coef, const float* mask, const float* x0, const float* noise_q, int S) {
+                         float* cur_t, float* cur_coef, const float* mask, const float* x0, const float* noise_q, int S,
+                         const float* emb_tab, int emb_w, float* cur_emb) {
     MAA_CHECK(nB <= 256, "ddim: at most 256 UNet rows per step");
     MAA_LAUNCH1(ddim_prepare_kernel, (long long)nB * (per + per_c), x, concat, B, nB, per, per_c, tab_t, tab_coef, step,
-                xin, cur_t, cur_coef, mask, x0, noise_q, S);
+                xin, cur_t, cur_coef, mask, x0, noise_q, S, emb_tab, emb_w, cur_emb);
 }
 void launch_ddim_step(const Ctx& ctx, const float* xin, long long per, long long per_in, const float* eps_u, const float* eps_c,
                       float scale, const float* coef, long long n, float* x_prev, const float* noise_p, float temperature, int S,

@@ -15,8 +15,15 @@ public:
     // classifier-free guidance: context rows [uncond (B) ; cond (B)] assembled in a buffer the UNet owns (it stays
     // valid for later forwards, e.g. the I2A time-embedding add), then set_context over 2B rows
     void set_context_cfg(Ctx& ctx, const float* d_uncond, const float* d_cond, int B, int L);
+    // emb_row: optional, the ResBlocks' time-embedding row of this step from emb_table() (one row for all samples: every
+    // sample of a DDIM step shares t); null: computed from t (and, I2A, the context) as the reference does per forward
     void forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
-                 float* out_nchw);
+                 float* out_nchw, const float* emb_row = nullptr);
+    // Linear(SiLU(time_embed(timestep_embedding(t)))) of every ResBlock for `rows` timesteps at once -> [rows, emb_width()]
+    // (openaimodel.py:725-726, 218-224): the sampling loop computes its S rows once instead of per step.  Not for the
+    // I2A variant, whose embedding also takes the sample's context (custom_openaimodel.py:352-354).
+    void emb_table(Ctx& ctx, const float* d_t, int rows, float* d_out);
+    int emb_width() const;
     const maa_unet_config& config() const;
     size_t weight_bytes() const;
     // context pointer remembered by set_context (needed by the I2A time-embedding add)

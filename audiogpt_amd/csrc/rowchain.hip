@@ -176,27 +176,6 @@ __global__ __launch_bounds__(NT) void rowchain_kernel(const RowChainArgs q) {
         }
     };
 
-    // ---- everything the stage-1 epilogue reads from global memory is requested NOW (accumulator layout: lane = column lrow
-    // of each 32-wide block, rows (r & 3) + 8 (r >> 2) + 4 lk): bias, LayerNorm gamma / beta and the residual rows travel while
-    // the K loop runs instead of costing a full memory latency between the stages (one wave per SIMD: nothing else hides it)
-    const int rowt = wm * 32 + 4 * lk;            // + (r & 3) + 8 (r >> 2): row inside the tile
-    long long mc[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + rowt + (r & 3) + 8 * (r >> 2);
-        mc[r] = m < q.M ? m : q.M - 1;
-    }
-    float bias[NI], lng[NI], lnb[NI], rs[NI][16];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = wn * (NI * 32) + j * 32 + lrow;
-        bias[j] = q.bias1 ? q.bias1[n] : 0.f;
-        lng[j] = q.ln_g ? q.ln_g[n] : 1.f;
-        lnb[j] = q.ln_g ? q.ln_b[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rs[j][r] = q.res1 ? q.res1[mc[r] * q.ldr1 + n] : 0.f;
-    }
-
     // ------------------------------------------------------------------------------------------ stage 1
     {
         // this wave's pieces of a chunk: lines 8 (wid IPW1 + j) + r8 of the stage; A lines first, then W1 lines.  Lane i of
@@ -302,46 +281,51 @@ __global__ __launch_bounds__(NT) void rowchain_kernel(const RowChainArgs q) {
     }
 
     // ------------------------------------------------------------------------------------------ stage-1 epilogue
+    // accumulator layout: lane holds column lrow of each 32-wide block, rows (r & 3) + 8 (r >> 2) + 4 lk
+    const int rowt = wm * 32 + 4 * lk;            // + (r & 3) + 8 (r >> 2): row inside the tile
+    long long mc[16];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        settle(bias[j]);
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + rowt + (r & 3) + 8 * (r >> 2);
+        mc[r] = m < q.M ? m : q.M - 1;
+    }
+    {
+        float bias[NI];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            settle(rs[j][r]);
-            const float v = acc[j][r] * 1.0f + bias[j];
-            acc[j][r] = q.res1 ? v + rs[j][r] : v;
+        for (int j = 0; j < NI; ++j) bias[j] = q.bias1 ? q.bias1[wn * (NI * 32) + j * 32 + lrow] : 0.f;
+        if (q.res1) {
+            // all of the residual's loads in flight together, waited for once (igemm_epilogue.h explains the cost otherwise)
+            float rs[NI][16];
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rs[j][r] = q.res1[mc[r] * q.ldr1 + wn * (NI * 32) + j * 32 + lrow];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                settle(bias[j]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    settle(rs[j][r]);
+                    acc[j][r] = (acc[j][r] * 1.0f + bias[j]) + rs[j][r];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                settle(bias[j]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] * 1.0f + bias[j];
+            }
         }
     }
     if (q.y) {
-        // fp32 rows, two columns per lane (igemm_epilogue.h's pair store): the lanes of an even / odd column pair swap one value
-        // per pair of rows, the even lane stores columns (n, n + 1) of the even row, the odd lane those of the odd row
-        const bool even = (lrow & 1) == 0;
-        const bool pair = (q.ldy & 1) == 0 && (reinterpret_cast<uintptr_t>(q.y) & 7) == 0;
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = wn * (NI * 32) + j * 32 + lrow;
-            if (pair) {
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    const float keep = even ? acc[j][2 * rp] : acc[j][2 * rp + 1];
-                    const float give = even ? acc[j][2 * rp + 1] : acc[j][2 * rp];
-                    const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, false));
-                    const int r = 2 * rp + (even ? 0 : 1);
-                    const int m = m0 + rowt + (r & 3) + 8 * (r >> 2);
-                    if (m < q.M) {
-                        typedef float f32x2 __attribute__((ext_vector_type(2)));
-                        const f32x2 v2 = even ? f32x2{keep, got} : f32x2{got, keep};
-                        *reinterpret_cast<f32x2*>(q.y + (long long)m * q.ldy + (n & ~1)) = v2;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + rowt + (r & 3) + 8 * (r >> 2);
-                    if (m < q.M) q.y[(long long)m * q.ldy + n] = acc[j][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + rowt + (r & 3) + 8 * (r >> 2);
+                if (m < q.M) q.y[(long long)m * q.ldy + wn * (NI * 32) + j * 32 + lrow] = acc[j][r];
             }
-        }
     }
 
     // ---- LayerNorm over the N columns of every row (two passes, fp32): a wave holds 32 NI of a row's columns -- block sum
@@ -402,8 +386,10 @@ __global__ __launch_bounds__(NT) void rowchain_kernel(const RowChainArgs q) {
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
+            const int n = wn * (NI * 32) + j * 32 + lrow;
+            const float g = q.ln_g[n], b = q.ln_b[n];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] - mean[r]) * rstd[r] * lng[j] + lnb[j];
+            for (int r = 0; r < 16; ++r) acc[j][r] = (acc[j][r] - mean[r]) * rstd[r] * g + b;
         }
         __syncthreads();          // every wave has read the partial sums: the region may now take the rows
     }
@@ -490,65 +476,46 @@ __global__ __launch_bounds__(NT) void rowchain_kernel(const RowChainArgs q) {
             slot_fill = (slot_fill + 1) & 3;
         });
         // ---- epilogue of column tile t (the next tile's first chunks are already on their way)
-        float bias2[NI];
+        float bias[NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bias2[j] = q.bias2 ? q.bias2[t * N + wn * (NI * 32) + j * 32 + lrow] : 0.f;
+        for (int j = 0; j < NI; ++j) bias[j] = q.bias2 ? q.bias2[t * N + wn * (NI * 32) + j * 32 + lrow] : 0.f;
         if (q.res2) {
-            float rs2[NI][16];
+            float rs[NI][16];
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) rs2[j][r] = q.res2[mc[r] * q.ldr2 + t * N + wn * (NI * 32) + j * 32 + lrow];
+                for (int r = 0; r < 16; ++r) rs[j][r] = q.res2[mc[r] * q.ldr2 + t * N + wn * (NI * 32) + j * 32 + lrow];
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                settle(bias2[j]);
+                settle(bias[j]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    settle(rs2[j][r]);
-                    acc[j][r] = (acc[j][r] * 1.0f + bias2[j]) + rs2[j][r];
+                    settle(rs[j][r]);
+                    acc[j][r] = (acc[j][r] * 1.0f + bias[j]) + rs[j][r];
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
-                settle(bias2[j]);
+                settle(bias[j]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] * 1.0f + bias2[j];
+                for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] * 1.0f + bias[j];
             }
         }
-        const bool zpair = !q.z_split && (q.ldz & 1) == 0 && (reinterpret_cast<uintptr_t>(q.z) & 7) == 0;
-        const bool zeven = (lrow & 1) == 0;
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int n = t * N + wn * (NI * 32) + j * 32 + lrow;
-            if (zpair) {          // 8-byte stores: see the stage-1 rows above
 #pragma unroll
-                for (int rp = 0; rp < 8; ++rp) {
-                    const float keep = zeven ? acc[j][2 * rp] : acc[j][2 * rp + 1];
-                    const float give = zeven ? acc[j][2 * rp + 1] : acc[j][2 * rp];
-                    const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, false));
-                    const int r = 2 * rp + (zeven ? 0 : 1);
-                    const int m = m0 + rowt + (r & 3) + 8 * (r >> 2);
-                    if (m < q.M) {
-                        typedef float f32x2 __attribute__((ext_vector_type(2)));
-                        const f32x2 v2 = zeven ? f32x2{keep, got} : f32x2{got, keep};
-                        *reinterpret_cast<f32x2*>(q.z + (long long)m * q.ldz + (n & ~1)) = v2;
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + rowt + (r & 3) + 8 * (r >> 2);
+                if (m < q.M) {
+                    if (q.z_split)
+                        store_split_pair(q.z + (long long)m * q.ldz, n, acc[j][r]);
+                    else
+                        q.z[(long long)m * q.ldz + n] = acc[j][r];
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + rowt + (r & 3) + 8 * (r >> 2);
-                    if (m < q.M) {
-                        if (q.z_split)
-                            store_split_pair(q.z + (long long)m * q.ldz, n, acc[j][r]);
-                        else
-                            q.z[(long long)m * q.ldz + n] = acc[j][r];
-                    }
-                }
+                acc[j][r] = 0.f;
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         }
     }
     wait_vmcnt<0>();          // (the trailing dummy copies) nothing may land in LDS after the workgroup has given it back

@@ -273,7 +273,7 @@ struct UNet::Impl {
         o1.KH = o1.KW = 3;
         o1.pad = 1;
         o1.rowadd = emb_out + r.emb_off;
-        o1.ld_rowadd = emb_all.Npad;
+        o1.ld_rowadd = emb_ld;
         const float* resid = nullptr;
         if (r.updown == 1) {          // openaimodel.py:212-214,256-261: avg-pool both h and x, then conv
             MAA_CHECK(!x2, "down ResBlock takes one source");
@@ -529,24 +529,40 @@ struct UNet::Impl {
         return h;
     }
 
-    void forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
-                 float* out_nchw) {
+    // rows = one per timestep: emb_layers(SiLU(time_embed(timestep_embedding(t)))) for every ResBlock (openaimodel.py:725-726,
+    // 218-224, 264) -> out [rows, emb_all.Npad].  `add` (I2A: context.squeeze(1), custom_openaimodel.py:352-354) is a residual
+    // of the second time_embed Linear.
+    void emb_rows(Ctx& ctx, const float* t, int rows, const float* add, float* out) {
         const int mc = cfg.model_channels;
-        // timestep embedding -> time_embed MLP (openaimodel.py:725-726)
-        float* te = ctx.ws.alloc_f((size_t)B * mc);
-        launch_timestep_embedding(ctx, t, B, mc, te);
-        float* e1 = ctx.ws.alloc_f((size_t)B * emb_dim);
-        linear_into(ctx, te, mc, B, mc, te0, nullptr, 0, e1, emb_dim);
-        float* emb = ctx.ws.alloc_f((size_t)B * emb_dim);
-        launch_silu(ctx, e1, (long long)B * emb_dim, e1);
-        // I2A adds context.squeeze(1) to the embedding (custom_openaimodel.py:352-354): a residual of the GEMM
-        linear_into(ctx, e1, emb_dim, B, emb_dim, te2, cfg.add_context_to_emb ? context : nullptr, emb_dim, emb, emb_dim);
-        // all ResBlock emb_layers at once: Linear(SiLU(emb)) (openaimodel.py:218-224, 264)
-        float* semb = ctx.ws.alloc_f((size_t)B * emb_dim);
-        launch_silu(ctx, emb, (long long)B * emb_dim, semb);
-        float* emb_out = ctx.ws.alloc_f((size_t)B * emb_all.Npad);
-        linear_into(ctx, semb, emb_dim, B, emb_dim, emb_all, nullptr, 0, emb_out, emb_all.Npad);
+        float* te = ctx.ws.alloc_f((size_t)rows * mc);
+        launch_timestep_embedding(ctx, t, rows, mc, te);
+        float* e1 = ctx.ws.alloc_f((size_t)rows * emb_dim);
+        linear_into(ctx, te, mc, rows, mc, te0, nullptr, 0, e1, emb_dim);
+        float* emb = ctx.ws.alloc_f((size_t)rows * emb_dim);
+        launch_silu(ctx, e1, (long long)rows * emb_dim, e1);
+        linear_into(ctx, e1, emb_dim, rows, emb_dim, te2, add, emb_dim, emb, emb_dim);
+        float* semb = ctx.ws.alloc_f((size_t)rows * emb_dim);
+        launch_silu(ctx, emb, (long long)rows * emb_dim, semb);
+        linear_into(ctx, semb, emb_dim, rows, emb_dim, emb_all, nullptr, 0, out, emb_all.Npad);
+    }
+    int emb_ld = 0;      // pitch between the samples' rows of the current forward's emb_out (0: one row for every sample)
 
+    // emb_row != null: the step's ResBlock time-embedding row computed beforehand (UNet::emb_table), shared by all samples
+    void forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
+                 float* out_nchw, const float* emb_row = nullptr) {
+        if (emb_row) {
+            emb_ld = 0;
+            forward_body(ctx, x_nchw, B, H, W, out_nchw, emb_row);
+            return;
+        }
+        float* emb_out = ctx.ws.alloc_f((size_t)B * emb_all.Npad);
+        emb_rows(ctx, t, B, cfg.add_context_to_emb ? context : nullptr, emb_out);
+        emb_ld = emb_all.Npad;
+        forward_body(ctx, x_nchw, B, H, W, out_nchw, emb_out);
+    }
+
+    void forward_body(Ctx& ctx, const float* x_nchw, int B, int H, int W, float* out_nchw, const float* emb_out) {
+        const int mc = cfg.model_channels;
         T4 h = alloc_t(ctx, B, H, W, cfg.in_channels);
         launch_nchw_to_nhwc(ctx, x_nchw, B, cfg.in_channels, H * W, h.p);
         std::vector<T4> hs;
@@ -625,10 +641,17 @@ void UNet::set_context_cfg(Ctx& ctx, const float* d_uncond, const float* d_cond,
 }
 
 void UNet::forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
-                   float* out_nchw) {
+                   float* out_nchw, const float* emb_row) {
     Impl& m = *impl_;
     PrecisionGuard pg(ctx, m.precision);
-    run_sized(ctx, [&] { m.forward(ctx, x_nchw, t, context, B, H, W, out_nchw); });
+    run_sized(ctx, [&] { m.forward(ctx, x_nchw, t, context, B, H, W, out_nchw, emb_row); });
+}
+int UNet::emb_width() const { return impl_->emb_all.Npad; }
+void UNet::emb_table(Ctx& ctx, const float* d_t, int rows, float* d_out) {
+    Impl& m = *impl_;
+    MAA_CHECK(!m.cfg.add_context_to_emb, "emb_table: this UNet's embedding depends on the sample's context");
+    PrecisionGuard pg(ctx, m.precision);
+    run_sized(ctx, [&] { m.emb_rows(ctx, d_t, rows, nullptr, d_out); });
 }
 
 }  // namespace maa
