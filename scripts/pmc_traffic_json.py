@@ -84,8 +84,10 @@ if section_name is None:
     if os.path.exists(out):          # keep the secondary workloads' tables of an earlier call on the same sources
         try:
             old = json.load(open(out))
-            if old.get("source_hash") == doc["source_hash"] and old.get("precision") == prec and "secondary" in old:
-                doc["secondary"] = old["secondary"]
+            keep = {k: v for k, v in old.get("secondary", {}).items()
+                    if v.get("source_hash") == doc["source_hash"] and v.get("precision") == prec}
+            if keep:                 # each section carries its own stamp (the file's top-level one may be an older round's)
+                doc["secondary"] = keep
         except Exception:
             pass
 else:
