@@ -35,7 +35,6 @@ struct FlashArgs {
     float* out;
     int ldo;
     int out_split;                // write split32 lines (the to_out projection reads them with no conversion)
-    int precise_exp;              // 1: libm expf instead of v_exp_f32 (kept for experiments; the library always passes 0)
     int causal;                   // query i sees keys 0 .. i only (OpenCLIP's text tower)
     long long o_bs;
     const float* zeros;
@@ -95,8 +94,8 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
         const int qrow = q0 + lq;
         const bool qok = qrow < a.Nq;
         const float* src = qp + (long long)(qok ? qrow : 0) * a.ldq;
-        // the softmax scale (and, on the exp2 path, log2 e) rides on Q: the scores leave the MFMA ready for the exponential
-        const float qs = a.precise_exp ? a.scale : a.scale * 1.4426950408889634f;
+        // the softmax scale and log2 e ride on Q: the scores leave the MFMA ready for v_exp_f32 (2^x)
+        const float qs = a.scale * 1.4426950408889634f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d = ks * 16 + lh * 8;
@@ -238,7 +237,7 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
             }
 
             // ---- online softmax for query lq: this lane's keys are kt*32 + (r&3) + 8*(r>>2) + 4*lh.  The scores are already
-            // scaled (natural-log units on the precise path, log2 units on the exp2 path); only a short last tile or a causal
+            // scaled, in log2 units; only a short last tile or a causal
             // mask needs the per-key test (uniform branch)
             float p[16];
             float mt = -INFINITY;
@@ -262,20 +261,11 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
             // after the first tiles, so the rescale of O is skipped for a wave whose lanes all kept their maximum (alpha == 1
             // exactly)
             float alpha, ls = 0.f;
-            if (a.precise_exp) {
-                alpha = expf(m_run - m_new);                  // first tile: exp(-inf) = 0
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);                  // first tile: exp2(-inf) = 0
     #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    p[r] = expf(p[r] - m_new);                // masked keys: exp(-inf) = 0
-                    ls += p[r];
-                }
-            } else {
-                alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    p[r] = __builtin_amdgcn_exp2f(p[r] - m_new);
-                    ls += p[r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(p[r] - m_new);                // masked keys: exp2(-inf) = 0
+                ls += p[r];
             }
             ls += __shfl_xor(ls, 32, 64);
             l_run = l_run * alpha + ls;
@@ -409,7 +399,6 @@ bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, co
     a.out = out;
     a.ldo = ldo;
     a.out_split = out_split;
-    a.precise_exp = 0;      // (v_exp_f32 path; the libm variant was an A/B knob, retired in round 4)
     a.causal = causal;
     a.o_bs = (long long)Nq * ldo;
     a.zeros = ctx.zeros;

@@ -445,8 +445,7 @@ Dma2Plan plan_impl(const Ctx& ctx, const IGemm& p) {
         if (*env == "off") return pl;
         int cfg = 0, ns = 4, pipe = 1, S = 1, kmin = 0, kmax = 1 << 30;
         const int k = std::sscanf(env->c_str(), "%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &kmax);
-        if (k >= 4) {
-            MAA_CHECK(cfg == 0 && ns == 4 && pipe == 1, "MAA_DMA2: the engine keeps one instantiation, \"0,4,1,S\"");
+        if (k >= 4) {      // (format validated by Tuning::load when the context was created)
             if (p.K < kmin) return pl;
             if (p.K <= kmax) {
                 pl.cfg = 0;

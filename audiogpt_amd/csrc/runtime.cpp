@@ -176,6 +176,21 @@ void Tuning::load() {
     snake_untiled = !get_s("MAA_SNAKE_UNTILED").empty();
     const std::string rc = get_s("MAA_ROWCHAIN");
     rowchain = rc.empty() || rc[0] != '0';
+    // a stale override in an older round's format ("2,2,0,1": tile, stages ...) is refused here, when the context is created
+    // (last, so that every other knob is in place), not by a check in the middle of a forward pass
+    auto check_dma2 = [](const std::string& name, std::string& v) {
+        if (v.empty() || v == "off") return;
+        int cfg = 0, ns = 4, pipe = 1, S = 1, kmin = 0, kmax = 0;
+        const int k = std::sscanf(v.c_str(), "%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &kmax);
+        if (k < 4 || cfg != 0 || ns != 4 || pipe != 1 || S < 1) {
+            const std::string bad = v;
+            v.clear();      // the context keeps running on the default policy if the caller catches the error
+            throw Error(name + "=\"" + bad + "\": expected \"off\" or \"0,4,1,S[,kmin[,kmax]]\" (the split-K engine keeps one "
+                        "instantiation: tile 0, 4 stages, pipelined; S = K slices)");
+        }
+    };
+    check_dma2("MAA_DMA2", dma2);
+    for (auto& kv : dma2_n) check_dma2("MAA_DMA2_N" + std::to_string(kv.first), kv.second);
 }
 
 void StepGraph::clear() {

@@ -60,8 +60,10 @@ int maa_ctx_set_stream(maa_ctx* ctx, void* hip_stream);
  * Storage, normalisations, softmax and every epilogue stay fp32 in all modes. */
 int maa_ctx_set_precision(maa_ctx* ctx, int mode);
 /* The tuning / test knobs of the environment (MAA_PP, MAA_PP1, MAA_DMA2, MAA_DMA2_N<n>, MAA_DMA2_PERSIST, MAA_PP_DBG,
- * MAA_OP_PRESPLIT) are parsed once, when a context is created; this parses them again (and drops the step
- * graph the sampler keeps).  For tests and A/B runs. */
+ * MAA_OP_PRESPLIT, MAA_DMA_NS_LOW, MAA_NO_DMA, MAA_NO_HALO, MAA_SNAKE_UNTILED, MAA_ROWCHAIN) are
+ * parsed in one place, when a context is created; this parses them again (and drops the step graph the sampler keeps).  A
+ * malformed MAA_DMA2 / MAA_DMA2_N<n> value fails here (and in maa_ctx_create) with a message naming the variable.  For tests
+ * and A/B runs. */
 int maa_ctx_reload_tuning(maa_ctx* ctx);
 /* bytes currently reserved for the activation workspace */
 int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out);

@@ -171,3 +171,21 @@ def test_persistent_workgroups_match_one_workgroup_per_item(ctx, variant):
     with forced(variant):
         z = ctx.op_linear(a, wl).cpu()
     check(f"dma2[{variant}]_persistent_linear_12480x320x960", z, F.linear(a, wl), TOL)
+
+
+def test_a_stale_override_is_refused_when_the_tuning_is_parsed(ctx):
+    """MAA_DMA2 in round 2's format ("2,2,0,1" = tile, stages, pipelining, slices of an instantiation that no longer exists)
+    must fail where the knobs are parsed -- context creation / reload_tuning -- with a message naming the variable, not as
+    a check inside a forward pass; the context then runs on the default policy."""
+    x = torch.randn(2, 320, 10, 78, generator=g(51))
+    w = torch.randn(320, 320, 3, 3, generator=g(52)) / math.sqrt(2880)
+    y0 = ctx.op_conv(x, w, None, pad=1).cpu()
+    os.environ["MAA_DMA2"] = "2,2,0,1"
+    try:
+        with pytest.raises(RuntimeError, match="MAA_DMA2"):
+            ctx.reload_tuning()
+        y1 = ctx.op_conv(x, w, None, pad=1).cpu()
+    finally:
+        os.environ.pop("MAA_DMA2", None)
+        ctx.reload_tuning()
+    assert torch.equal(y0, y1)
