@@ -94,9 +94,10 @@ class Context:
                                             bytes=rows[i].bytes) for i in range(n.value)}
 
     def calib(self):
-        """Box calibration (csrc/calib.hip): what a fixed MFMA loop and a fixed device copy reach on this box right now."""
+        """Box calibration (csrc/calib.hip): what a fixed MFMA loop, a fixed device copy and fixed re-reads out of L2 / out of
+        the Infinity Cache reach on this box right now."""
         out = {}
-        for kind, key in ((0, "mfma_bf16_tflops"), (1, "copy_gbs")):
+        for kind, key in ((0, "mfma_bf16_tflops"), (1, "copy_gbs"), (2, "l2_read_gbs"), (3, "infinity_cache_read_gbs")):
             v = C.c_double()
             L.check(self.lib.maa_calib(self.h, kind, C.byref(v)))
             out[key] = v.value

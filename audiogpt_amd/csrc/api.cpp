@@ -559,7 +559,7 @@ int maa_op_conv(maa_ctx* ctx, const float* d_x, int B, int Cin, int H, int W, co
 int maa_calib(maa_ctx* ctx, int kind, double* out_value) {
     return guarded([&] {
         bind(ctx);
-        MAA_CHECK(out_value && (kind == 0 || kind == 1), "bad calib arguments");
+        MAA_CHECK(out_value && kind >= 0 && kind <= 3, "bad calib arguments");
         *out_value = maa::calib_run(ctx->c, kind);
     });
 }

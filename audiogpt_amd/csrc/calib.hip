@@ -3,6 +3,9 @@
 //   kind 0  back-to-back v_mfma_f32_32x32x16_bf16 on eight independent accumulators per wave, 16 waves per CU -> TFLOP/s
 //           (the dense bf16 MFMA rate the box sustains at the clock its power limit allows; 2500 at 2.4 GHz)
 //   kind 1  float4 copy of 256 MiB -> GB/s read + written (HBM3E: 8 TB/s peak, ~6.3 TB/s for this pattern)
+//   kind 2  every workgroup re-reads its own 64 KiB (16 MiB in all: inside the 8 x 4 MiB of L2, past the L1) -> GB/s out of L2
+//   kind 3  128 MiB re-read by the whole grid (past L2, inside the 256 MiB Infinity Cache) -> GB/s out of the fabric side
+//           (kinds 2 and 3, round 4: the boxes that run the short-K / slab kernels 1.5-2x slower have kinds 0 and 1 normal)
 // Not part of the reference's interface; nothing in the product path calls it.
 #include "maa_internal.h"
 
@@ -39,6 +42,35 @@ __global__ __launch_bounds__(256) void calib_copy_kernel(const float4* __restric
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) dst[i] = src[i];
 }
 
+// sum of float4s read from `src`: a workgroup walks its own `per_wg4` float4s `reps` times (kind 2), or the whole grid walks
+// n4 float4s grid-stride `reps` times (kind 3: per_wg4 = 0)
+__global__ __launch_bounds__(1024) void calib_read_kernel(const float4* __restrict__ src, long long n4, int per_wg4, int reps,
+                                                          float* sink) {
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < reps; ++r) {
+        if (per_wg4) {
+            const float4* p = src + (long long)blockIdx.x * per_wg4;
+            for (int i = threadIdx.x; i < per_wg4; i += blockDim.x) {
+                const float4 v = p[i];
+                s.x += v.x;
+                s.y += v.y;
+                s.z += v.z;
+                s.w += v.w;
+            }
+        } else {
+            for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+                const float4 v = src[i];
+                s.x += v.x;
+                s.y += v.y;
+                s.z += v.z;
+                s.w += v.w;
+            }
+        }
+        __syncthreads();
+    }
+    if (s.x + s.y + s.z + s.w == 12345.678f) sink[0] = s.x;      // (never true)
+}
+
 }  // namespace
 
 double calib_run(const Ctx& ctx, int kind) {
@@ -58,6 +90,23 @@ double calib_run(const Ctx& ctx, int kind) {
         MAA_HIP(hipEventElapsedTime(&ms, e0, e1));
         const double flops = (double)reps * blocks * 4.0 * iters * 8.0 * (2.0 * 32 * 32 * 16);
         value = flops / (ms * 1e-3) / 1e12;
+    } else if (kind == 2 || kind == 3) {
+        const size_t bytes = kind == 2 ? (size_t)cus * (64 << 10) : (size_t)128 << 20;
+        const int reps = kind == 2 ? 256 : 16;
+        const int per_wg4 = kind == 2 ? (64 << 10) / 16 : 0;
+        const int blocks = kind == 2 ? cus : 2 * cus;
+        void* src = nullptr;
+        MAA_HIP(hipMalloc(&src, bytes));
+        MAA_HIP(hipMemsetAsync(src, 0, bytes, ctx.stream));
+        const long long n4 = (long long)(bytes / 16);
+        hipLaunchKernelGGL(calib_read_kernel, dim3(blocks), dim3(1024), 0, ctx.stream, (const float4*)src, n4, per_wg4, 2, ctx.zeros);
+        MAA_HIP(hipEventRecord(e0, ctx.stream));
+        hipLaunchKernelGGL(calib_read_kernel, dim3(blocks), dim3(1024), 0, ctx.stream, (const float4*)src, n4, per_wg4, reps, ctx.zeros);
+        MAA_HIP(hipEventRecord(e1, ctx.stream));
+        MAA_HIP(hipEventSynchronize(e1));
+        MAA_HIP(hipEventElapsedTime(&ms, e0, e1));
+        MAA_HIP(hipFree(src));
+        value = (double)bytes * reps / (ms * 1e-3) / 1e9;
     } else {
         const size_t bytes = (size_t)256 << 20;
         const int reps = 8;

@@ -124,7 +124,8 @@ struct Tuning {
     bool no_dma = false;                    // MAA_NO_DMA: every bf16 contraction on the register-staged engine (bit-identity tests)
     bool no_halo = false;                   // MAA_NO_HALO: the narrow vocoder stages through the implicit GEMM (bit-identity test)
     bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
-    bool rowchain = true;                   // MAA_ROWCHAIN=0: the transformer's short-K linears stay separate launches (A/B, tests)
+    bool rowchain = false;                  // MAA_ROWCHAIN=1: the transformer's linear -> LayerNorm -> linear chains as one launch each (rowchain.hip; off since the
+                                            // round-4 boxes that run it 1.8x slower than the others -- DESIGN.md 3.2c)
     void load();
 };
 

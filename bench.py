@@ -193,6 +193,7 @@ class BoxSampler:
         import glob
         import threading
         self.sclk, self.power, self.period = [], [], period
+        self.other = {"mclk": [], "fclk": [], "socclk": []}      # memory / fabric / SoC clock levels, where the driver exposes them
         self._stop = threading.Event()
         self._thread = None
         self.card = None
@@ -259,6 +260,13 @@ class BoxSampler:
                 self.sclk.append(v)
         except Exception:
             pass
+        for k, v in self.other.items():
+            try:
+                c = self.parse_sclk(open(os.path.join(self.card, "pp_dpm_" + k)).read())
+                if c is not None:
+                    v.append(c)
+            except Exception:
+                pass
         for h in self._hw:
             for f in ("power1_average", "power1_input"):
                 try:
@@ -287,9 +295,11 @@ class BoxSampler:
         def med(v):
             return sorted(v)[len(v) // 2] if v else None
         return {"sclk_mhz_median": med(self.sclk), "sclk_mhz_min": min(self.sclk) if self.sclk else None,
+                "mclk_mhz_median": med(self.other["mclk"]), "fclk_mhz_median": med(self.other["fclk"]),
+                "socclk_mhz_median": med(self.other["socclk"]),
                 "socket_power_w_median": med(self.power), "socket_power_w_max": max(self.power) if self.power else None,
                 "samples": len(self.sclk), "pci_bus_id": self.bdf, "matched_by": self.matched_by,
-                "source": "amdgpu sysfs (pp_dpm_sclk, hwmon power) of %s, sampled during the timed region" % self.card}
+                "source": "amdgpu sysfs (pp_dpm_sclk / mclk / fclk / socclk, hwmon power) of %s, sampled during the timed region" % self.card}
 
 
 def roofline_of(rows, precision):
@@ -845,8 +855,9 @@ def main(argv=None):
     if rank == 0 and not stub:
         try:
             calib = pipe.ctx.calib()
-            calib["note"] = ("csrc/calib.hip on the first replica's stream: dense bf16 MFMA loop (peak 2500 TFLOP/s at 2.4 GHz) "
-                             "and a 256 MiB float4 copy (read + written bytes)")
+            calib["note"] = ("csrc/calib.hip on the first replica's stream: dense bf16 MFMA loop (peak 2500 TFLOP/s at 2.4 GHz), "
+                             "a 256 MiB float4 copy (read + written bytes), every workgroup re-reading its own 64 KiB (L2), "
+                             "128 MiB re-read by the whole grid (Infinity Cache)")
         except Exception as e:      # never lose the line to the calibration
             calib = {"error": str(e)[:200]}
         barrier()

@@ -349,8 +349,9 @@ int maa_resampler_destroy(maa_resampler* r);
 int maa_resampler_forward(maa_ctx* ctx, maa_resampler* r, const float* d_wav, int B, int n, float* d_out);
 
 /* Box calibration for the benchmark's `box.calib` record (no counterpart in the reference): kind 0 = a fixed register-only
- * loop of dense bf16 MFMAs -> TFLOP/s the box sustains, kind 1 = a fixed 256 MiB device copy -> GB/s (read + written).  Timed
- * with HIP events on the context's stream. */
+ * loop of dense bf16 MFMAs -> TFLOP/s the box sustains, kind 1 = a fixed 256 MiB device copy -> GB/s (read + written), kind 2 =
+ * every workgroup re-reading its own 64 KiB (out of L2) -> GB/s, kind 3 = a 128 MiB buffer re-read by the whole grid (past L2,
+ * inside the Infinity Cache) -> GB/s.  Timed with HIP events on the context's stream. */
 int maa_calib(maa_ctx* ctx, int kind, double* out_value);
 
 /* ---- single-operator entry points (parity tests and profiling of individual kernels) ------------ */

@@ -196,11 +196,14 @@ def test_bench_box_sampler_reads_amdgpu_sysfs(tmp_path):
     dev = tmp_path / "card0" / "device"
     (dev / "hwmon" / "hwmon3").mkdir(parents=True)
     (dev / "pp_dpm_sclk").write_text("0: 132Mhz\n1: 2230Mhz *\n")
+    (dev / "pp_dpm_mclk").write_text("0: 900Mhz\n1: 2000Mhz *\n")
+    (dev / "pp_dpm_fclk").write_text("0: 1200Mhz\n1: 1800Mhz *\n")      # (no pp_dpm_socclk: reported as None)
     (dev / "hwmon" / "hwmon3" / "power1_average").write_text("1350000000\n")
     with bench.BoxSampler(root=str(tmp_path), period=0.02) as sm:
         time.sleep(0.2)
     r = sm.summary()
     assert r["sclk_mhz_median"] == 2230 and r["sclk_mhz_min"] == 2230 and abs(r["socket_power_w_median"] - 1350.0) < 1e-6 and r["samples"] >= 2
+    assert r["mclk_mhz_median"] == 2000 and r["fclk_mhz_median"] == 1800 and r["socclk_mhz_median"] is None
     with bench.BoxSampler(root=str(tmp_path / "nothing")) as sm:
         pass
     assert sm.summary()["sclk_mhz_median"] is None and sm.summary()["samples"] == 0
