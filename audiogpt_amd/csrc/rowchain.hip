@@ -534,7 +534,7 @@ void launch_one(const Ctx& ctx, const RowChainArgs& q) {
 }  // namespace
 
 bool rowchain_covers(const Ctx& ctx, const RowChain& d) {
-    if (ctx.dtype == 0 || !ctx.tune.rowchain) return false;
+    if (ctx.dtype == 0) return false;      // (whether the UNet USES the chains is the caller's policy: Tuning::rowchain, unet.cpp)
     const int N = d.w1.N;
     if (N != 320 && N != 256) return false;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };

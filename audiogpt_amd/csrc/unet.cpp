@@ -324,6 +324,7 @@ struct UNet::Impl {
     bool run_st_chained(Ctx& ctx, const STW& s, const T4& x, const float* xn, T4& out) {
         const int B = x.B, HW = x.H * x.W, inner = s.heads * s.dh;
         const long long M = (long long)B * HW;
+        if (!ctx.tune.rowchain) return false;      // opt-in (MAA_ROWCHAIN=1): DESIGN.md 3.2c
         if (s.blocks.size() != 1 || inner != s.ch || !split_for_gemm(ctx, inner) || !flash_attention_covers(ctx, s.dh)) return false;
         const STBlockW& b = s.blocks[0];
         float* y = ctx.ws.alloc_f((size_t)M * inner);

@@ -21,6 +21,7 @@ for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE" "SQ_VALU_MF
   rm -rf gpurun_out/pmc_${tag}_$n gpurun_out/pmc_${tag}_$n.log
 done
 python scripts/pmc_traffic_json.py gpurun_out/${tag}_${prec}_pmc_fetch_write.txt $prec $STEPS profiles/pmc_traffic.json && cp profiles/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.json
+[ -n "$SKIP_BENCH" ] && exit 0      # (re-stamp only: the bench line of these kernels already exists)
 ( time python bench.py --precision $prec > gpurun_out/${tag}_${prec}_bench.json 2> gpurun_out/bench_$tag.err ) 2> gpurun_out/${tag}_bench_wall_time.txt; tail -3 gpurun_out/${tag}_bench_wall_time.txt
 python -c "
 import json; d=json.load(open('gpurun_out/${tag}_${prec}_bench.json')); print('VALUE', d['value'], d['ms_per_step']); r=d['roofline']; print({k:r[k] for k in ('kernel','achieved','peak','frac','avg_launch_us','launches','traffic')}); print(d['cpu_baseline'])
