@@ -401,3 +401,32 @@ def test_product_tree_never_touches_the_oracle_or_the_reference_tree():
     runtime += [os.path.join(root, "tests", f) for f in os.listdir(os.path.join(root, "tests")) if f.endswith(".py")]
     for path in runtime:
         assert REF not in open(path, encoding="utf-8").read(), path + " would need the reference tree at run time"
+
+
+def test_pmc_traffic_tables_keep_their_own_source_stamp(tmp_path):
+    """scripts/pmc_traffic_json.py (profiles/pmc_traffic.json, what bench.py's `roofline.traffic` reads): the secondary
+    workloads' tables are stamped one by one, a primary pass keeps the sections measured on the same sources whatever the
+    file's older top-level stamp says (round 4: the sections were dropped because the file still carried round 3's hash), and
+    drops a section measured on other sources."""
+    import json
+    import subprocess
+    import sys
+    from audiogpt_amd.build import _source_hash
+    prof = os.path.join(ROOT, "profiles")
+    out = tmp_path / "pmc_traffic.json"
+    out.write_text(json.dumps({"precision": "bf16x3", "source_hash": "0" * 64, "ddim_steps": 4, "kernels": {}}))   # an older round's file
+    run = lambda *a: subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic_json.py"), *a], check=True,
+                                    capture_output=True, timeout=120)
+    run(os.path.join(prof, "r4_hifigan64_pmc_fetch_write.txt"), "bf16x3", "1", str(out), "--section", "hifigan64")
+    run(os.path.join(prof, "r4_mixed_pmc_fetch_write.txt"), "bf16x3", "4", str(out), "--section", "mixed")
+    d = json.loads(out.read_text())
+    assert set(d["secondary"]) == {"hifigan64", "mixed"} and d["secondary"]["mixed"]["source_hash"] == _source_hash()
+    d["secondary"]["mixed"]["source_hash"] = "1" * 64          # pretend this one was taken on other sources
+    out.write_text(json.dumps(d))
+    run(os.path.join(prof, "r4_bf16x3_pmc_fetch_write.txt"), "bf16x3", "4", str(out))
+    d = json.loads(out.read_text())
+    assert d["source_hash"] == _source_hash() and set(d.get("secondary", {})) == {"hifigan64"}
+    e = d["kernels"]["igemm_pp_bf16x3<256x160,splitK>"]
+    assert e["launches_per_ddim_step"] == 24.0 and 1.2e8 < e["hbm_bytes_per_launch"] < 1.6e8 and 0.3 < e["mfma_busy"] < 0.6
+    k = d["secondary"]["hifigan64"]["kernels"]["igemm_pp_bf16x3<256x128>"]
+    assert k["launches_per_unit"] == 36.0 and k["hbm_bytes_per_launch"] > 4e9
