@@ -98,7 +98,7 @@ class MakeAnAudio:
         results are concatenated in prompt order.  Every sample is an independent trajectory and the kernels are batch
         invariant bit for bit (a clip alone == the clip inside its batch: tests/test_gpu_config2.py), so this returns exactly
         what pipes[0].generate would for the whole batch -- sooner, because two half-size batches side by side fill the chip
-        better than one (profiles/r4_split_probe_subbatches_on_streams.txt: 8 prompts in 885 ms instead of 953)."""
+        better than one (profiles/r4/r4_split_probe_subbatches_on_streams.txt: 8 prompts in 885 ms instead of 953)."""
         from concurrent.futures import ThreadPoolExecutor
         n, m = x_T.shape[0], len(pipes)
         bounds = [(k * n) // m for k in range(m + 1)]

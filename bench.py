@@ -302,6 +302,21 @@ class BoxSampler:
                 "source": "amdgpu sysfs (pp_dpm_sclk / mclk / fclk / socclk, hwmon power) of %s, sampled during the timed region" % self.card}
 
 
+# What the calibration reads reach on the boxes that gave the fast-class numbers (profiles/README.md: 23.4 TB/s out of L2,
+# 6.5 - 6.6 TB/s out of the Infinity Cache, 5.2 - 5.4 TB/s copy).  A box is put in the slow class when a read falls below 85 % of
+# that: the kernels that lose on such boxes are the L2 -> LDS-bound ones, which neither the MFMA loop nor the
+# copy loop tells apart.
+BOX_CLASS_REF = {"l2_read_gbs": 23400.0, "infinity_cache_read_gbs": 6500.0, "copy_gbs": 5200.0, "mfma_bf16_tflops": 2250.0}
+
+
+def box_class(calib, frac=0.85):
+    """'fast' or 'slow(<which reads are low>)' from box.calib; None if the calibration did not run."""
+    if not isinstance(calib, dict) or "error" in calib:
+        return None
+    low = [k for k, ref in BOX_CLASS_REF.items() if isinstance(calib.get(k), (int, float)) and calib[k] < frac * ref]
+    return "fast" if not low else "slow(%s)" % ",".join(low)
+
+
 def roofline_of(rows, precision):
     """Roofline object of the dominant implicit-GEMM kernel out of a maa_prof table (hipEvents on the library's stream)."""
     total_ms = sum(r["ms"] for r in rows.values())
@@ -346,10 +361,134 @@ def attach_traffic(roof, precision, section=None, units=None):
     per = None if not e else e.get("launches_per_ddim_step", e.get("launches_per_unit"))
     if e and t.get("precision") == precision and t.get("source_hash") == _source_hash() and per and abs(per - mine) <= 0.03 * mine:
         roof["traffic"] = e["hbm_bytes_per_launch"]
-        roof["traffic_note"] = t["note"]
+        roof["traffic_source"] = "profiles/pmc_traffic.json"
+        roof["traffic_note"] = ("NOT measured in this run: `traffic` / `mfma_busy` are attached from profiles/pmc_traffic.json (rocprofv3 PMC "
+                                "passes of this same binary -- source hash, precision and launch mix matched -- taken on the builder's box). "
+                                + t["note"])
         roof["mfma_busy"] = e.get("mfma_busy")      # SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, same PMC call
     else:
         roof["traffic_note"] = "profiles/pmc_traffic.json does not match this binary / launch mix: not reported"
+
+
+LINE_LIMIT = 6144          # the driver keeps the last 8.6 kB of stdout: the ONE JSON line must fit with room to spare
+_ROOF_KEEP = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_mfma_issue_peak", "traffic", "mfma_busy",
+              "traffic_source", "launches", "avg_launch_us")
+_CPU_KEEP = ("value", "unit", "cores", "kind")
+_PARITY_KEEP = ("mel_l1", "wav_rms", "gate", "meets_gate")
+
+
+def _sig(v, n=5):
+    """Floats to n significant digits (the detail file keeps full precision)."""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    return float("%.*g" % (n, v))
+
+
+def _pick(d, keys):
+    return {k: _sig(d[k]) for k in keys if k in (d or {}) and d[k] is not None} if d else None
+
+
+def slim_workload(r, top=False):
+    """The part of one workload's record that goes into the stdout line: value / ms_per_step / dtype / config.workload and the
+    three attachments (roofline, cpu_baseline, parity) cut down to their numbers.  Everything else -- per-kernel time tables,
+    traffic notes, sample descriptions -- stays in the detail file."""
+    if "error" in r:
+        return {"error": r["error"][:160]}
+    o = {k: _sig(r[k]) for k in ("value", "unit", "ms_per_step", "dtype", "steps") if k in r}
+    if not top:
+        o["workload"] = str((r.get("config") or {}).get("workload", ""))[:100]
+    if r.get("one_batch_in_flight"):
+        o["one_batch_in_flight"] = _pick(r["one_batch_in_flight"], ("value", "ms_per_step"))
+    for k in ("T2A_txt2audio", "I2A_img2audio"):
+        if k in r:
+            o[k] = _pick(r[k], ("ms", "clip_seconds", "realtime_factor"))
+    if r.get("roofline"):
+        o["roofline"] = _pick(r["roofline"], _ROOF_KEEP)
+        wp = r["roofline"].get("whole_pass")
+        if wp:
+            o["roofline"]["whole_pass_frac"] = _sig(wp["frac_of_mfma_peak"])
+    if r.get("cpu_baseline"):
+        o["cpu_baseline"] = _pick(r["cpu_baseline"], _CPU_KEEP)
+    if r.get("parity") and _pick(r["parity"], _PARITY_KEEP):
+        o["parity"] = _pick(r["parity"], _PARITY_KEEP)
+    return o
+
+
+def slim_line(result, detail_path=None, limit=LINE_LIMIT):
+    """The ONE stdout JSON line (<= `limit` bytes) out of the full result record.  Top level: the driver's contract fields, the
+    headline's roofline / cpu_baseline (with a one-line `sample`), `one_batch_in_flight` (BASELINE configs[1] literally: one
+    batch of 8 owning the GPU), `one_batch_two_streams`, `box` with its calibration reads, and per secondary workload a
+    slim_workload record.  `detail` names the file that holds the full record."""
+    o = {k: result[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in result}
+    for k in ("value", "ms_per_step"):
+        o[k] = _sig(o[k], 7)
+    cfg = dict(result.get("config") or {})
+    if "workload" in cfg:
+        cfg["workload"] = cfg["workload"][:230]
+    o["config"] = cfg
+    for k in ("comm_ms_per_step", "batch_latency_ms"):
+        if k in result:
+            o[k] = {a: _sig(b) for a, b in result[k].items()}
+    if result.get("roofline"):
+        o["roofline"] = _pick(result["roofline"], _ROOF_KEEP)
+        ai = result["roofline"].get("all_igemm")
+        if ai:
+            o["roofline"]["all_igemm_tflops"] = _sig(ai["achieved"])
+            o["roofline"]["all_igemm_share"] = _sig(ai["share_of_kernel_time"])
+        wp = result["roofline"].get("whole_pass")
+        if wp:
+            o["roofline"]["whole_pass_frac"] = _sig(wp["frac_of_mfma_peak"])
+        kt = result["roofline"].get("kernel_time_ms") or {}
+        tot = sum(kt.values()) or 1.0
+        o["roofline"]["top_kernel_share"] = {k[:40]: _sig(v / tot, 3) for k, v in list(kt.items())[:5]}
+    if result.get("cpu_baseline"):
+        o["cpu_baseline"] = _pick(result["cpu_baseline"], _CPU_KEEP)
+        o["cpu_baseline"]["sample"] = str(result["cpu_baseline"].get("sample", ""))[:160]
+    if result.get("one_batch_in_flight"):
+        o["one_batch_in_flight"] = _pick(result["one_batch_in_flight"], ("value", "ms_per_step", "steps"))
+    if result.get("one_batch_two_streams"):
+        o["one_batch_two_streams"] = _pick(result["one_batch_two_streams"], ("value", "ms_per_step", "bit_identical_to_one_stream"))
+    if result.get("box"):
+        b = result["box"]
+        o["box"] = _pick(b, ("sclk_mhz_median", "mclk_mhz_median", "fclk_mhz_median", "socket_power_w_median", "pci_bus_id", "class"))
+        if isinstance(b.get("calib"), dict):
+            o["box"]["calib"] = {k: _sig(v) for k, v in b["calib"].items() if isinstance(v, (int, float))}
+    for k in ("ranks_seen", "per_rank_value", "last_gather_shape"):
+        if k in result:
+            o[k] = result[k]
+    if "secondary" in result:
+        o["secondary"] = {k: slim_workload(v) for k, v in result["secondary"].items()}
+    if detail_path:
+        o["detail"] = detail_path
+    line = json.dumps(o, separators=(",", ":"))
+    if len(line) > limit:          # never exceed the capture: drop the optional parts, most verbose first
+        for path in (("roofline", "top_kernel_share"), ("cpu_baseline", "sample"), ("config", "workload"), ("data",)):
+            d = o
+            for k in path[:-1]:
+                d = d.get(k) or {}
+            d.pop(path[-1], None)
+            line = json.dumps(o, separators=(",", ":"))
+            if len(line) <= limit:
+                break
+    assert len(line) <= limit, "bench line is %d bytes (> %d)" % (len(line), limit)
+    return line
+
+
+def emit(result, args):
+    """Full record -> gpurun_out/bench_detail.json (and --json-out), slim line -> stdout."""
+    detail_rel = os.path.join("gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, detail_rel), "w") as f:
+            json.dump(result, f)
+    except OSError:
+        detail_rel = None
+    if getattr(args, "json_out", None):
+        with open(args.json_out, "w") as f:
+            f.write(json.dumps(result))
+    sys.stderr.write("[bench] full record (per-kernel tables, notes, samples): %s\n" % (detail_rel or "not written"))
+    print(json.dumps(result) if getattr(args, "full_line", False) else slim_line(result, detail_rel), flush=True)
 
 
 def run_hifigan64(dev, precision, steps, warmup, cpu_base=True, roofline=True):
@@ -712,7 +851,9 @@ def main(argv=None):
                     help="prompt batches in flight per GPU: consecutive steps (independent batches of 8 prompts) run on this many "
                          "pipeline replicas / HIP streams, as a serving loop would overlap requests; 1 = strictly one after another")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)      # tests: this file's control flow on CPU / gloo
-    ap.add_argument("--json-out", default=None, help=argparse.SUPPRESS)              # tests: also write the line to a file
+    ap.add_argument("--json-out", default=None, help="also write the FULL record (what gpurun_out/bench_detail.json holds) to this file")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the full record on stdout instead of the <= 6 kB line (per-kernel tables included: ~25 kB)")
     args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -731,13 +872,12 @@ def main(argv=None):
     Event = _NullEvent if stub else torch.cuda.Event
     if args.workload == "hifigan64":
         assert world == 1, "the vocoder-only workload is a single-GPU configuration"
-        print(json.dumps(run_hifigan64(dev, args.precision, args.steps, args.warmup, not args.no_cpu_baseline,
-                                       not args.no_roofline)), flush=True)
+        emit(run_hifigan64(dev, args.precision, args.steps, args.warmup, not args.no_cpu_baseline, not args.no_roofline), args)
         return
     if args.workload == "mixed":
         assert world == 1, "run one mixed batch per GPU (replicas) -- no collective in this workload"
-        print(json.dumps(run_mixed(dev, args.precision, args.steps, args.warmup, args.prompts_per_gpu, args.ddim_steps,
-                                   not args.no_roofline, not args.no_cpu_baseline)), flush=True)
+        emit(run_mixed(dev, args.precision, args.steps, args.warmup, args.prompts_per_gpu, args.ddim_steps,
+                       not args.no_roofline, not args.no_cpu_baseline), args)
         return
     dist = None
     if world > 1:
@@ -753,7 +893,7 @@ def main(argv=None):
     from audiogpt_amd.pipeline import MakeAnAudio
     from audiogpt_amd.shard import broadcast_conditioning, gather_waveforms, ranks_seen, run_in_flight, start_codes
     # One batch of 8 prompts leaves much of the chip idle (its kernels are short and latency-bound: two independent
-    # batches side by side finish in 1.57x the time of one, profiles/r2_dual_stream_probe.txt), so consecutive steps of the
+    # batches side by side finish in 1.57x the time of one, profiles/r2/r2_dual_stream_probe.txt), so consecutive steps of the
     # benchmark -- independent prompt batches, each sampled exactly as BASELINE configs[1] says -- are kept `inflight` at
     # a time on as many pipeline replicas (own HIP stream, workspace and weights), like a server overlapping requests.
     # Collectives stay on this thread, in step order.
@@ -852,15 +992,15 @@ def main(argv=None):
         v.clear()
     # box calibration right before the timed region (rank 0): what a fixed MFMA loop and a fixed copy reach on this box now
     calib = None
-    if rank == 0 and not stub:
+    if rank == 0:
         try:
-            calib = pipe.ctx.calib()
+            calib = pipe.ctx.calib() if not stub else {"stub": 1.0}
             calib["note"] = ("csrc/calib.hip on the first replica's stream: dense bf16 MFMA loop (peak 2500 TFLOP/s at 2.4 GHz), "
                              "a 256 MiB float4 copy (read + written bytes), every workgroup re-reading its own 64 KiB (L2), "
                              "128 MiB re-read by the whole grid (Infinity Cache)")
         except Exception as e:      # never lose the line to the calibration
             calib = {"error": str(e)[:200]}
-        barrier()
+    barrier()      # EVERY rank (a collective): rank 0's calibration loops must not run into the other ranks' timed region
     sampler = BoxSampler(dev) if (rank == 0 and not stub) else None
     if sampler is not None:
         sampler.__enter__()
@@ -907,6 +1047,7 @@ def main(argv=None):
         result["box"] = sampler.summary()
         if calib is not None:
             result["box"]["calib"] = calib
+            result["box"]["class"] = box_class(calib)
     if world > 1:
         # proof of what an N > 1 line ran on: the device identity of every rank (PCI address; must be N distinct ones) and each
         # rank's own rate over its own clock (the line's value uses the slowest rank's time)
@@ -997,10 +1138,7 @@ def main(argv=None):
         if stub:
             result["data"] = "stub pipeline on CPU (control-flow test): not a measurement"
             result["last_gather_shape"] = list(out.shape) if out is not None else None
-        print(json.dumps(result), flush=True)
-        if args.json_out:
-            with open(args.json_out, "w") as f:
-                f.write(json.dumps(result))
+        emit(result, args)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

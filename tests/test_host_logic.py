@@ -158,11 +158,11 @@ def test_pmc_traffic_derivation_and_staleness_guard(tmp_path):
 
 
 def test_bench_line_contract_of_a_gpu_run():
-    """A bench line measured on the MI355X this round (profiles/r3_bf16x3_bench.json, written by scripts/gpu_profile.sh)
+    """A bench line measured on the MI355X this round (profiles/r3/r3_bf16x3_bench.json, written by scripts/gpu_profile.sh)
     carries every field of the driver's contract plus roofline, cpu_baseline and the secondary workloads, states its method
     in the metric string, and its arithmetic is self-consistent."""
     import json
-    path = os.path.join(ROOT, "profiles", "r3_bf16x3_bench.json")
+    path = os.path.join(ROOT, "profiles", "r3", "r3_bf16x3_bench.json")
     if not os.path.exists(path):
         import pytest
         pytest.skip("no round-3 bench line committed yet")
@@ -412,7 +412,7 @@ def test_pmc_traffic_tables_keep_their_own_source_stamp(tmp_path):
     import subprocess
     import sys
     from audiogpt_amd.build import _source_hash
-    prof = os.path.join(ROOT, "profiles")
+    prof = os.path.join(ROOT, "profiles", "r4")
     out = tmp_path / "pmc_traffic.json"
     out.write_text(json.dumps({"precision": "bf16x3", "source_hash": "0" * 64, "ddim_steps": 4, "kernels": {}}))   # an older round's file
     run = lambda *a: subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_traffic_json.py"), *a], check=True,
@@ -430,3 +430,58 @@ def test_pmc_traffic_tables_keep_their_own_source_stamp(tmp_path):
     assert e["launches_per_ddim_step"] == 24.0 and 1.2e8 < e["hbm_bytes_per_launch"] < 1.6e8 and 0.3 < e["mfma_busy"] < 0.6
     k = d["secondary"]["hifigan64"]["kernels"]["igemm_pp_bf16x3<256x128>"]
     assert k["launches_per_unit"] == 36.0 and k["hbm_bytes_per_launch"] > 4e9
+
+
+def test_bench_stdout_line_fits_the_drivers_capture(capsys):
+    """the driver keeps the last 8.6 kB of stdout, so the ONE JSON line must stay under 6 kB and still carry,
+    per workload, value / ms_per_step / roofline{kernel, frac, achieved, traffic, mfma_busy, avg_launch_us} / cpu_baseline /
+    parity, plus one_batch_in_flight, one_batch_two_streams and box.calib at the top level.  Checked on the largest full record
+    committed (round 4's 17 kB line) and on bench.main's own stub path."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r4", "r4_bf16x3_bench.json")))
+    # worst case: every workload with every attachment, long kernel names, traffic on every roofline
+    for w in full["secondary"].values():
+        if "roofline" in w:
+            w["roofline"].setdefault("traffic", 123456789.0)
+            w["roofline"]["traffic"] = w["roofline"]["traffic"] or 123456789.0
+            w["roofline"]["mfma_busy"] = 0.123456
+            w["roofline"]["traffic_source"] = "profiles/pmc_traffic.json"
+    full["box"]["class"] = "slow(l2_read_gbs,infinity_cache_read_gbs)"
+    line = bench.slim_line(full, "gpurun_out/bench_detail.json")
+    assert len(line) <= bench.LINE_LIMIT == 6144 and "\n" not in line
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "one_batch_in_flight", "one_batch_two_streams", "box"):
+        assert k in d, k
+    assert d["value"] == pytest.approx(full["value"], rel=1e-6) and d["config"]["batches_in_flight"] == 3
+    assert d["one_batch_in_flight"]["value"] == pytest.approx(full["one_batch_in_flight"]["value"], rel=1e-4)
+    assert set(d["box"]["calib"]) >= {"mfma_bf16_tflops", "copy_gbs", "l2_read_gbs", "infinity_cache_read_gbs"}
+    r = d["roofline"]
+    assert r["kernel"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["traffic"] > 0 and r["avg_launch_us"] > 0
+    assert "kernel_time_ms" not in r and "traffic_note" not in r
+    assert set(d["secondary"]) == {"hifigan64", "mixed", "t2a_bf16", "t2a_bigvgan", "tool_latency"}
+    for name, w in d["secondary"].items():
+        assert w["value"] > 0 and w["cpu_baseline"]["value"] > 0 and w["cpu_baseline"]["kind"] == "port", name
+        assert 0 < w["roofline"]["frac"] < 1 and w["roofline"]["kernel"] and w["roofline"]["traffic"] > 0, name
+    assert d["secondary"]["t2a_bf16"]["parity"]["meets_gate"] is False and d["secondary"]["t2a_bigvgan"]["parity"]["meets_gate"] is True
+    assert d["secondary"]["t2a_bf16"]["one_batch_in_flight"]["value"] > 0
+    # the stub path of main() prints exactly one line, through the same function
+    bench.main(["--stub-cpu", "--steps", "2", "--warmup", "1", "--inflight", "2"])
+    out = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(out) == 1 and len(out[0]) <= bench.LINE_LIMIT
+    assert json.loads(out[0])["detail"].endswith("bench_detail.json")
+
+
+def test_box_class_thresholds():
+    """bench.box_class: a box whose L2 / Infinity-Cache reads fall under 85 % of the fast-class figures is labelled slow."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    fast = {"mfma_bf16_tflops": 2290.4, "copy_gbs": 5195.1, "l2_read_gbs": 23413.0, "infinity_cache_read_gbs": 6604.3}
+    assert bench.box_class(fast) == "fast"
+    assert bench.box_class(dict(fast, l2_read_gbs=15000.0)) == "slow(l2_read_gbs)"
+    assert bench.box_class(dict(fast, infinity_cache_read_gbs=4000.0, l2_read_gbs=1.0)) == "slow(l2_read_gbs,infinity_cache_read_gbs)"
+    assert bench.box_class({"error": "x"}) is None and bench.box_class(None) is None
