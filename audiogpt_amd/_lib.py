@@ -101,7 +101,7 @@ EXPORTS = [
     "maa_encoder_text_cls", "maa_clap_audio_create", "maa_clap_audio_destroy", "maa_clap_audio_embed", "maa_clap_similarity",
     "maa_spectral_create", "maa_spectral_destroy", "maa_spectral_forward", "maa_resampler_create", "maa_resampler_destroy",
     "maa_resampler_forward", "maa_op_linear", "maa_op_conv", "maa_op_groupnorm", "maa_op_layernorm",
-    "maa_op_attention", "maa_op_conv_transpose1d", "maa_op_snake_aa", "maa_op_bench_conv", "maa_op_rowchain", "maa_calib",
+    "maa_op_attention", "maa_op_conv_transpose1d", "maa_op_snake_aa", "maa_op_bench_conv", "maa_calib",
 ]
 
 _lib = None
@@ -174,7 +174,6 @@ def load():
         "maa_op_snake_aa": [vp, vp, ci, ci, ci, fp, fp, ci, vp],
         "maa_op_bench_conv": [vp, ci, ci, ci, ci, ci, ci, ci, ci, C.POINTER(C.c_float)],
         "maa_calib": [vp, ci, C.POINTER(C.c_double)],
-        "maa_op_rowchain": [vp, vp, ci, ci, ci, fp, fp, vp, vp, fp, fp, cf, vp, fp, fp, ci, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)

@@ -125,38 +125,6 @@ class Context:
         L.check(self.lib.maa_op_linear(self.h, L.dptr(a), M, K, wp, bp, N, int(geglu), L.dptr(y)))
         return y
 
-    def op_rowchain(self, a, w1, b1=None, res1=None, ln=None, eps=1e-5, w2=None, b2=None, res2=None, want_y=True,
-                    want_t=False):
-        """The row-chain engine on its own: y = a w1^T + b1 (+res1); t = LayerNorm(y; ln = (gamma, beta)) or y;
-        z = t w2^T + b2 (+res2).  Returns (y or None, t or None, z or None)."""
-        a = _f32(a, self.device)
-        M, K1 = a.shape
-        N = w1.shape[0]
-        keep = []
-
-        def host(t):
-            if t is None:
-                return None
-            ht, hp = L.host_f32(t)
-            keep.append(ht)
-            return hp
-
-        def dev(t):
-            return None if t is None else L.dptr(_f32(t, self.device))
-
-        r1 = _f32(res1, self.device) if res1 is not None else None
-        r2 = _f32(res2, self.device) if res2 is not None else None
-        y = torch.empty(M, N, device=self.device) if want_y else None
-        t = torch.empty(M, N, device=self.device) if want_t else None
-        N2 = w2.shape[0] if w2 is not None else 0
-        z = torch.empty(M, N2, device=self.device) if w2 is not None else None
-        L.check(self.lib.maa_op_rowchain(self.h, L.dptr(a), M, K1, N, host(w1), host(b1),
-                                         L.dptr(r1) if r1 is not None else None, L.dptr(y) if y is not None else None,
-                                         host(ln[0]) if ln else None, host(ln[1]) if ln else None, float(eps),
-                                         L.dptr(t) if t is not None else None, host(w2), host(b2), N2,
-                                         L.dptr(r2) if r2 is not None else None, L.dptr(z) if z is not None else None))
-        return y, t, z
-
     def op_conv(self, x, w, b=None, stride=1, pad=0, dil=1, up=False, leaky=0.0, out_hw=None):
         """x [B,Cin,H,W]; w [Cout,Cin,KH,KW]; returns [B,Cout,Ho,Wo]."""
         x = _f32(x, self.device)

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libaudiogpt_mi355x.so")
-SOURCES = ["igemm_f32.hip", "igemm_bf16.hip", "igemm_dma.hip", "igemm_dma2.hip", "igemm_pp.hip", "rowchain.hip", "calib.hip", "nsf.hip", "diffsinger.hip", "halo_conv1d.hip", "encoders.hip", "spectral.hip", "flash_attn.hip", "norm.hip", "misc.hip", "runtime.cpp", "blocks.cpp", "unet.cpp", "vae.cpp",
+SOURCES = ["igemm_f32.hip", "igemm_bf16.hip", "igemm_dma.hip", "igemm_dma2.hip", "igemm_pp.hip", "calib.hip", "nsf.hip", "diffsinger.hip", "halo_conv1d.hip", "encoders.hip", "spectral.hip", "flash_attn.hip", "norm.hip", "misc.hip", "runtime.cpp", "blocks.cpp", "unet.cpp", "vae.cpp",
            "vocoder.cpp", "diffnet.cpp", "encoders.cpp", "clap_audio.cpp", "ddim.cpp", "api.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"]

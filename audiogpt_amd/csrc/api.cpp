@@ -564,62 +564,6 @@ int maa_calib(maa_ctx* ctx, int kind, double* out_value) {
     });
 }
 
-int maa_op_rowchain(maa_ctx* ctx, const float* d_a, int M, int K1, int N, const float* h_w1, const float* h_b1,
-                    const float* d_res1, float* d_y, const float* h_ln_g, const float* h_ln_b, float eps, float* d_t,
-                    const float* h_w2, const float* h_b2, int N2, const float* d_res2, float* d_z) {
-    return guarded([&] {
-        bind(ctx);
-        MAA_CHECK(d_a && h_w1 && M > 0 && K1 > 0 && N > 0, "bad op_rowchain arguments");
-        MAA_CHECK((h_ln_g == nullptr) == (h_ln_b == nullptr), "op_rowchain: gamma and beta come together");
-        MAA_CHECK(!h_w2 || (d_z && N2 > 0), "op_rowchain: stage 2 needs its output");
-        maa::Ctx& c = ctx->c;
-        MAA_CHECK(c.dtype != 0, "op_rowchain: the row-chain engine runs in the bf16 precision modes");
-        OneShot s;
-        s.add("w1", h_w1, {N, K1});
-        if (h_b1) s.add("b1", h_b1, {N});
-        if (h_w2) s.add("w2", h_w2, {N2, N});
-        if (h_w2 && h_b2) s.add("b2", h_b2, {N2});
-        maa::WeightStore ws(true);
-        maa::PackedW w1 = ws.pack_conv(s.sd, "w1", h_b1 ? "b1" : "", 1, 1), w2;
-        if (h_w2) w2 = ws.pack_conv(s.sd, "w2", h_b2 ? "b2" : "", 1, 1);
-        float *g = nullptr, *b = nullptr;
-        if (h_ln_g) {
-            g = ws.upload(std::vector<float>(h_ln_g, h_ln_g + N));
-            b = ws.upload(std::vector<float>(h_ln_b, h_ln_b + N));
-        }
-        maa::run_sized(c, [&] {
-            float* sp = c.ws.alloc_f((size_t)M * K1);
-            float* tsp = d_t ? c.ws.alloc_f((size_t)M * N) : nullptr;
-            maa::launch_split32_pack(c, d_a, M, K1, sp);
-            maa::RowChain d;
-            d.M = M;
-            d.a = sp;
-            d.lda = K1;
-            d.w1 = w1;
-            d.res1 = d_res1;
-            d.ldr1 = N;
-            d.y = d_y;
-            d.ldy = N;
-            d.ln_g = g;
-            d.ln_b = b;
-            d.eps = eps;
-            d.t_out = tsp;
-            d.ldt = N;
-            if (h_w2) {
-                d.w2 = &w2;
-                d.res2 = d_res2;
-                d.ldr2 = N;
-                d.z = d_z;
-                d.ldz = N2;
-            }
-            MAA_CHECK(c.ws.dry || maa::rowchain_covers(c, d), "op_rowchain: shape not covered by the row-chain engine");
-            if (!c.ws.dry) maa::launch_rowchain(c, d);
-            if (d_t) maa::launch_split32_unpack(c, tsp, M, N, d_t);
-        });
-        MAA_HIP(hipStreamSynchronize(c.stream));
-    });
-}
-
 int maa_op_groupnorm(maa_ctx* ctx, const float* d_x, int B, int C, int HW, const float* h_gamma, const float* h_beta,
                      float eps, int silu, float* d_y) {
     return guarded([&] {

@@ -124,8 +124,6 @@ struct Tuning {
     bool no_dma = false;                    // MAA_NO_DMA: every bf16 contraction on the register-staged engine (bit-identity tests)
     bool no_halo = false;                   // MAA_NO_HALO: the narrow vocoder stages through the implicit GEMM (bit-identity test)
     bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
-    bool rowchain = false;                  // MAA_ROWCHAIN=1: the transformer's linear -> LayerNorm -> linear chains as one launch each (rowchain.hip; off since the
-                                            // round-4 boxes that run it 1.8x slower than the others -- DESIGN.md 3.2c)
     void load();
 };
 
@@ -318,31 +316,6 @@ struct PackedW {
     int ld = 0, nk = 0;
     int split = 0;          // 1: rows of w are split32 lines (row pitch ld floats)
 };
-
-// Row-chain engine (rowchain.hip): per 64-row block  y = a.W1^T + b1 (+res1);  t = LayerNorm(y) or y;  z = t.W2^T + b2 (+res2),
-// with the intermediate rows kept on the CU.  N = w1.N must be the whole row (320 or 256); w2.N a multiple of it.
-struct RowChain {
-    int M = 0;
-    const float* a = nullptr;        // split32 rows [M, w1.K], pitch lda floats
-    int lda = 0;
-    PackedW w1;
-    const float* res1 = nullptr;     // fp32 [M, N], pitch ldr1
-    int ldr1 = 0;
-    float* y = nullptr;              // optional fp32 copy of the stage-1 rows (the residual of a later layer)
-    int ldy = 0;
-    const float* ln_g = nullptr;     // LayerNorm between the stages (null: none)
-    const float* ln_b = nullptr;
-    float eps = 1e-5f;
-    float* t_out = nullptr;          // optional split32 copy of the (normalised) rows, pitch ldt
-    int ldt = 0;
-    const PackedW* w2 = nullptr;     // stage 2 (null: none)
-    const float* res2 = nullptr;     // fp32 [M, N] (only when w2->N == N)
-    int ldr2 = 0;
-    float* z = nullptr;              // [M, w2->N] fp32, or split32 rows when z_split
-    int ldz = 0, z_split = 0;
-};
-bool rowchain_covers(const Ctx& ctx, const RowChain& d);
-void launch_rowchain(const Ctx& ctx, const RowChain& d);
 
 // Conv1d(C, C, k, dilation) with "same" padding for the narrow vocoder stages (C = 32 / 64), bf16x3: the input tile is
 // staged once in LDS and every tap reads it at a row offset (halo_conv1d.hip).  false: not covered, use the implicit GEMM.

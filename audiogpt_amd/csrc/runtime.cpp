@@ -174,8 +174,6 @@ void Tuning::load() {
     no_dma = !get_s("MAA_NO_DMA").empty();
     no_halo = !get_s("MAA_NO_HALO").empty();
     snake_untiled = !get_s("MAA_SNAKE_UNTILED").empty();
-    const std::string rc = get_s("MAA_ROWCHAIN");
-    rowchain = !rc.empty() && rc[0] != '0';
     // a stale override in an older round's format ("2,2,0,1": tile, stages ...) is refused here, when the context is created
     // (last, so that every other knob is in place), not by a check in the middle of a forward pass
     auto check_dma2 = [](const std::string& name, std::string& v) {

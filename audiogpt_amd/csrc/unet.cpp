@@ -317,86 +317,6 @@ struct UNet::Impl {
         return out;
     }
 
-    // The 10 x 78 level (the row is 320 / 256 channels wide): the block's short-K linears as four row-chain launches with the
-    // LayerNorms on the accumulators (rowchain.hip) -- 15 launches become 9 and the intermediate rows stay on the CU.
-    //   proj_in -> norm1 -> qkv | attn1 | to_out(+x) -> norm2 -> to_q | attn2 | to_out(+x) -> norm3 | GEGLU | ff.net.2(+x) -> proj_out(+x_in)
-    // (attention.py:196-215, 250-261).  false: the level / mode is not covered, run_st takes the launch-per-layer path.
-    bool run_st_chained(Ctx& ctx, const STW& s, const T4& x, const float* xn, T4& out) {
-        const int B = x.B, HW = x.H * x.W, inner = s.heads * s.dh;
-        const long long M = (long long)B * HW;
-        if (!ctx.tune.rowchain) return false;      // opt-in (MAA_ROWCHAIN=1): DESIGN.md 3.2c
-        if (s.blocks.size() != 1 || inner != s.ch || !split_for_gemm(ctx, inner) || !flash_attention_covers(ctx, s.dh)) return false;
-        const STBlockW& b = s.blocks[0];
-        float* y = ctx.ws.alloc_f((size_t)M * inner);
-        float* qkv = ctx.ws.alloc_f((size_t)M * 3 * inner);
-        float* o = ctx.ws.alloc_f((size_t)M * inner);
-        float* y1 = ctx.ws.alloc_f((size_t)M * inner);
-        float* q = ctx.ws.alloc_f((size_t)M * inner);
-        float* y2 = ctx.ws.alloc_f((size_t)M * inner);
-        float* ln = ctx.ws.alloc_f((size_t)M * inner);
-        float* g = ctx.ws.alloc_f((size_t)M * 4 * inner);
-        RowChain c1, c2, c3, c4;
-        c1.M = c2.M = c3.M = c4.M = (int)M;
-        c1.a = xn;
-        c1.lda = s.ch;
-        c1.w1 = s.proj_in;
-        c1.y = y;
-        c1.ldy = inner;
-        c1.ln_g = b.ln1g;
-        c1.ln_b = b.ln1b;
-        c1.w2 = &b.qkv1;
-        c1.z = qkv;
-        c1.ldz = 3 * inner;
-        c2.a = o;
-        c2.lda = inner;
-        c2.w1 = b.out1;
-        c2.res1 = y;
-        c2.ldr1 = inner;
-        c2.y = y1;
-        c2.ldy = inner;
-        c2.ln_g = b.ln2g;
-        c2.ln_b = b.ln2b;
-        c2.w2 = &b.q2;
-        c2.z = q;
-        c2.ldz = inner;
-        c3.a = o;
-        c3.lda = inner;
-        c3.w1 = b.out2;
-        c3.res1 = y1;
-        c3.ldr1 = inner;
-        c3.y = y2;
-        c3.ldy = inner;
-        c3.ln_g = b.ln3g;
-        c3.ln_b = b.ln3b;
-        c3.t_out = ln;
-        c3.ldt = inner;
-        c4.a = g;
-        c4.lda = 4 * inner;
-        c4.w1 = b.ff2;
-        c4.res1 = y2;
-        c4.ldr1 = inner;
-        c4.w2 = &s.proj_out;
-        c4.res2 = x.p;
-        c4.ldr2 = s.ch;
-        c4.z = out.p;
-        c4.ldz = s.ch;
-        if (!(rowchain_covers(ctx, c1) && rowchain_covers(ctx, c2) && rowchain_covers(ctx, c3) && rowchain_covers(ctx, c4))) return false;
-        if (!split_for_gemm(ctx, 4 * inner)) return false;
-        const float scale = 1.0f / std::sqrt((float)s.dh);
-        launch_rowchain(ctx, c1);
-        attention_into(ctx, qkv, 3 * inner, s.dh, qkv + inner, 3 * inner, s.dh, qkv + 2 * inner, 3 * inner, s.dh, B, s.heads,
-                       s.dh, HW, HW, scale, o, inner, 1);
-        launch_rowchain(ctx, c2);
-        MAA_CHECK(ctx.ws.dry || (kv_cache[b.kv_slot] && kv_batch == B), "set_context must precede forward (batch)");
-        const float* kv = kv_cache[b.kv_slot];
-        attention_into(ctx, q, inner, s.dh, kv, 2 * inner, s.dh, kv + inner, 2 * inner, s.dh, B, s.heads, s.dh, HW, kv_len, scale,
-                       o, inner, 1);
-        launch_rowchain(ctx, c3);
-        linear_into(ctx, ln, inner, M, inner, b.ff1, nullptr, 0, g, 4 * inner, /*geglu=*/1, 0, M, 1);
-        launch_rowchain(ctx, c4);
-        return true;
-    }
-
     T4 run_st(Ctx& ctx, const STW& s, const T4& x) {
         const int B = x.B, HW = x.H * x.W, inner = s.heads * s.dh;
         const long long M = (long long)B * HW;
@@ -405,14 +325,6 @@ struct UNet::Impl {
         float* xn = ctx.ws.alloc_f((size_t)M * s.ch);
         const bool sp_in = split_for_gemm(ctx, s.ch), sp = split_for_gemm(ctx, inner);
         launch_groupnorm(ctx, x.p, s.ch, s.ch, nullptr, 0, 0, B, HW, 32, s.ng, s.nb, 1e-6f, 0, xn, sp_in);
-        if (sp_in) {
-            const size_t mk2 = ctx.ws.mark();
-            if (run_st_chained(ctx, s, x, xn, out)) {
-                ctx.ws.release(mk);
-                return out;
-            }
-            ctx.ws.release(mk2);
-        }
         float* y = ctx.ws.alloc_f((size_t)M * inner);
         linear_into(ctx, xn, s.ch, M, s.ch, s.proj_in, nullptr, 0, y, inner, 0, 0, sp_in ? M : 0);
         const float scale = 1.0f / std::sqrt((float)s.dh);

@@ -30,14 +30,22 @@ def start_codes(seed, n_total, shape, world=1, rank=0):
     return torch.from_numpy(x[lo:hi]).to(torch.float32)
 
 
-def broadcast_conditioning(c_all, uc_row, n_local, device, dist=None, src=0, shape=None, mode="scatter"):
+def _single(dist, force):
+    """True when the collective can be skipped: no process group, or a world of one (unless `force`: the world-size-1 RCCL
+    test drives scatter / broadcast / gather / all_gather_object down their collective branches on the one GPU it has)."""
+    if dist is None or not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and not force
+
+
+def broadcast_conditioning(c_all, uc_row, n_local, device, dist=None, src=0, shape=None, mode="scatter", force=False):
     """C1.  c_all [n_total, L, D] and uc_row [1, L, D] exist on `src` (None elsewhere).
     Returns (c_local [n_local, L, D], uc_local [n_local, L, D]) on every rank.
     `shape` = (n_total, L, D) when every rank already knows it (a serving loop with fixed batch geometry): skips the
     metadata broadcast and its device -> host synchronisation.
     mode "scatter" (default): `src` sends rank r its own block only (one grouped send/recv on RCCL; blocks of ragged jobs
     are padded to the largest); "broadcast": the whole tensor to every rank, sliced locally."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(dist, force):
         return c_all[:n_local].contiguous(), uc_row.expand(n_local, -1, -1).contiguous()
     world, rank = dist.get_world_size(), dist.get_rank()
     if shape is not None:
@@ -77,11 +85,11 @@ def broadcast_conditioning(c_all, uc_row, n_local, device, dist=None, src=0, sha
     return c_local, uc_row.expand(n_local, -1, -1).contiguous()
 
 
-def ranks_seen(device, dist=None):
+def ranks_seen(device, dist=None, force=False):
     """Identity of the device every rank runs on, gathered to all ranks: the first N > 1 run can check that RCCL really had N
     distinct GPUs (a mis-set HIP_VISIBLE_DEVICES puts every rank on one).  Returns {"ids": [...], "n_distinct": k}."""
     mine = device_identity(device)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(dist, force):
         return {"ids": [mine], "n_distinct": 1}
     ids = [None] * dist.get_world_size()
     dist.all_gather_object(ids, mine)
@@ -107,10 +115,10 @@ def device_identity(device):
     return "cuda-index:%d" % (device.index if device.index is not None else torch.cuda.current_device())
 
 
-def gather_waveforms(wav_local, dist=None, dst=0, counts=None):
+def gather_waveforms(wav_local, dist=None, dst=0, counts=None, force=False):
     """C2.  wav_local [n_local, T] -> [n_total, T] on `dst` (None elsewhere); ragged shards allowed.
     `counts` = per-rank row counts when known up front (skips the count exchange and its host synchronisation)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single(dist, force):
         return wav_local
     world, rank = dist.get_world_size(), dist.get_rank()
     if counts is None:

@@ -850,6 +850,9 @@ def main(argv=None):
     ap.add_argument("--inflight", type=int, default=3,
                     help="prompt batches in flight per GPU: consecutive steps (independent batches of 8 prompts) run on this many "
                          "pipeline replicas / HIP streams, as a serving loop would overlap requests; 1 = strictly one after another")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="initialise the process group and issue C1 scatter / broadcast, C2 gather, the barriers and ranks_seen even "
+                         "with ONE rank (RCCL exercised on the one GPU a test box has: tests/test_gpu_rccl.py)")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)      # tests: this file's control flow on CPU / gloo
     ap.add_argument("--json-out", default=None, help="also write the FULL record (what gpurun_out/bench_detail.json holds) to this file")
     ap.add_argument("--full-line", action="store_true",
@@ -880,9 +883,11 @@ def main(argv=None):
                        not args.no_roofline, not args.no_cpu_baseline), args)
         return
     dist = None
-    if world > 1:
+    force = args.force_collectives
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if stub:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -954,7 +959,7 @@ def main(argv=None):
     def conditioning():
         e0, e1 = Event(enable_timing=True), Event(enable_timing=True)
         e0.record()
-        c, uc = broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape)          # C1: RCCL broadcast (no-op at N = 1)
+        c, uc = broadcast_conditioning(c_all, uc_row, n, dev, dist, shape=cond_shape, force=force)   # C1: RCCL scatter + bcast (no-op at N = 1)
         e1.record()
         comm_events["C1_broadcast"].append((e0, e1))
         ready = Event()
@@ -969,7 +974,7 @@ def main(argv=None):
             wav.record_stream(cur)
         e0, e1 = Event(enable_timing=True), Event(enable_timing=True)
         e0.record()
-        out = gather_waveforms(wav, dist, counts=counts)                                       # C2: gather to rank 0
+        out = gather_waveforms(wav, dist, counts=counts, force=force)                          # C2: gather to rank 0
         e1.record()
         comm_events["C2_gather"].append((e0, e1))
         return out
@@ -1019,7 +1024,7 @@ def main(argv=None):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    seen = ranks_seen(dev, dist) if world > 1 else None
+    seen = ranks_seen(dev, dist, force=force) if (world > 1 or force) else None
 
     # device time of the two collectives of a step (events on the main thread's stream, this rank): their share of a step is
     # what the first multi-GPU run should look at before anything else
@@ -1048,7 +1053,7 @@ def main(argv=None):
         if calib is not None:
             result["box"]["calib"] = calib
             result["box"]["class"] = box_class(calib)
-    if world > 1:
+    if world > 1 or force:
         # proof of what an N > 1 line ran on: the device identity of every rank (PCI address; must be N distinct ones) and each
         # rank's own rate over its own clock (the line's value uses the slowest rank's time)
         result["ranks_seen"] = seen
@@ -1135,6 +1140,9 @@ def main(argv=None):
             except Exception as e:      # never lose the headline line to a secondary workload
                 result["secondary"][name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if rank == 0:
+        if out is not None:      # identity of the last step's gathered waveforms (bit-identity checks between arrangements)
+            import hashlib
+            result["wav_sha16"] = hashlib.sha256(out.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
         if stub:
             result["data"] = "stub pipeline on CPU (control-flow test): not a measurement"
             result["last_gather_shape"] = list(out.shape) if out is not None else None

@@ -30,8 +30,6 @@ LABELS = {  # bench.py / maa_prof label -> (rocprof kernel prefixes, prefix whos
     "igemm_pp_bf16x3<256x128>": (["igemm_pp_kernel<2, 2, 2, 2"], "igemm_pp_kernel<2, 2, 2, 2"),
     "igemm_pp_bf16x3<256x160>": (["igemm_pp_kernel<1, 5, 4, 1"], "igemm_pp_kernel<1, 5, 4, 1"),
     "igemm_pp1_bf16x3<256x128>": (["igemm_pp1_kernel<2, 2, 2, 2"], "igemm_pp1_kernel<2, 2, 2, 2"),
-    "igemm_rowchain_bf16x3<64x320>": (["rowchain_kernel<5, 3"], "rowchain_kernel<5, 3"),
-    "igemm_rowchain_bf16x3<64x256>": (["rowchain_kernel<4, 3"], "rowchain_kernel<4, 3"),
     "igemm_bf16x3<128x128>": (["igemm_bf16_kernel<128, 128, 2, 2, 3"], "igemm_bf16_kernel<128, 128, 2, 2, 3"),
     "igemm_bf16x3<128x64>": (["igemm_bf16_kernel<128, 64, 2, 2, 3"], "igemm_bf16_kernel<128, 64, 2, 2, 3"),
     "igemm_bf16x3<64x64>": (["igemm_bf16_kernel<64, 64, 2, 2, 3"], "igemm_bf16_kernel<64, 64, 2, 2, 3"),

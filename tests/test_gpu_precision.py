@@ -197,7 +197,7 @@ def test_dma_engine_bit_identical(tmp_path):
         e = dict(os.environ)
         e.pop("MAA_NO_DMA", None)
         e.pop("MAA_DMA2", None)
-        e.update({"MAA_PP": "off", "MAA_PP1": "off", "MAA_ROWCHAIN": "0"})      # (the fused row chains would take the 10x78 linears away from the engines compared here)
+        e.update({"MAA_PP": "off", "MAA_PP1": "off"})      # (here)
         e.update(env)
         r = subprocess.run([sys.executable, "-c", _DMA_SCRIPT.format(root=root, golden=golden, out=out)], env=e,
                            capture_output=True, text=True, timeout=600)

@@ -16,7 +16,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "audiogpt_amd", "csrc")
-FILES = ["igemm_pp.hip", "rowchain.hip", "igemm_dma.hip", "igemm_dma2.hip", "igemm_bf16.hip", "igemm_f32.hip", "flash_attn.hip", "halo_conv1d.hip"]
+FILES = ["igemm_pp.hip", "igemm_dma.hip", "igemm_dma2.hip", "igemm_bf16.hip", "igemm_f32.hip", "flash_attn.hip", "halo_conv1d.hip"]
 
 
 def _hipcc():
@@ -111,7 +111,7 @@ def test_no_scratch_inside_any_mfma_loop(asm):
 def test_engines_use_the_instructions_the_design_names(asm):
     def count(f, pat):
         return len(re.findall(pat, asm[f]))
-    for f in ("igemm_pp.hip", "rowchain.hip", "igemm_dma.hip", "igemm_dma2.hip", "halo_conv1d.hip"):
+    for f in ("igemm_pp.hip", "igemm_dma.hip", "igemm_dma2.hip", "halo_conv1d.hip"):
         assert count(f, r"global_load_lds_dwordx4|global_load_lds") > 0, f
         assert count(f, r"v_mfma_f32_32x32x16_bf16") > 0, f
     assert count("igemm_bf16.hip", r"v_mfma_f32_32x32x16_bf16") > 0 and count("igemm_bf16.hip", r"global_load_lds") == 0

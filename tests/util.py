@@ -38,3 +38,11 @@ def check(name, got, ref, rtol_max, atol_mean=None):
     if atol_mean is not None:
         assert mean <= atol_mean, f"{name}: mean abs err {mean:.3e} > {atol_mean:.1e}"
     return r
+
+
+def free_port():
+    """A TCP port that is free right now on 127.0.0.1 (process-group rendezvous of the multi-process tests)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
