@@ -73,6 +73,12 @@ class Context:
         L.check(self.lib.maa_ctx_set_precision(self.h, self.PRECISIONS[precision]))
         self.precision = precision
 
+    def set_cfg_split(self, mode):
+        """Classifier-free guidance inside `ddim_sample`: True -> the two halves of the UNet batch as two lanes (two branches of
+        the captured step graph), False -> one stream, None -> the default policy (two lanes unless MAA_CFG_SPLIT=0).  The
+        results are the same bit for bit."""
+        L.check(self.lib.maa_ctx_set_cfg_split(self.h, -1 if mode is None else int(bool(mode))))
+
     def synchronize(self):
         L.check(self.lib.maa_ctx_synchronize(self.h))
 

@@ -124,7 +124,14 @@ int maa_ctx_create(int device_id, void* hip_stream, maa_ctx** out) {
             throw maa::Error("hipMalloc: zero page");
         }
         c->c.zeros = static_cast<float*>(z);
-        c->c.tune.load();
+        try {
+            c->c.tune.load();
+        } catch (...) {      // a malformed override: nothing of the half-built context survives the error
+            (void)hipFree(z);
+            if (c->owns_stream) (void)hipStreamDestroy(c->c.stream);
+            delete c;
+            throw;
+        }
         *out = c;
     });
 }
@@ -168,6 +175,14 @@ int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out) {
     });
 }
 
+int maa_ctx_set_cfg_split(maa_ctx* ctx, int mode) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(mode >= -1 && mode <= 1, "cfg_split: -1 (default policy), 0 (one stream) or 1 (two lanes)");
+        ctx->c.cfg_split = mode;
+    });
+}
+
 int maa_ctx_set_precision(maa_ctx* ctx, int mode) {
     return guarded([&] {
         bind(ctx);
@@ -183,6 +198,10 @@ int maa_prof_begin(maa_ctx* ctx, int detail) {
         ctx->c.prof->detail = detail;
         ctx->c.prof->pending.clear();
         ctx->c.prof->next = 0;
+        if (ctx->c.side) {      // (the second lane of a CFG step gets its own table when a step first forks under profiling)
+            delete ctx->c.side->prof;
+            ctx->c.side->prof = nullptr;
+        }
     });
 }
 int maa_prof_end(maa_ctx* ctx, maa_prof_row* rows, int max_rows, int* n_rows) {
@@ -192,6 +211,23 @@ int maa_prof_end(maa_ctx* ctx, maa_prof_row* rows, int max_rows, int* n_rows) {
         auto agg = ctx->c.prof->collect(ctx->c.stream);
         delete ctx->c.prof;
         ctx->c.prof = nullptr;
+        if (ctx->c.side && ctx->c.side->prof) {      // the launches of the second CFG lane, merged by name
+            for (auto& r : ctx->c.side->prof->collect(ctx->c.side->stream)) {
+                bool found = false;
+                for (auto& a : agg)
+                    if (a.name == r.name) {
+                        a.launches += r.launches;
+                        a.ms += r.ms;
+                        a.flops += r.flops;
+                        a.bytes += r.bytes;
+                        found = true;
+                        break;
+                    }
+                if (!found) agg.push_back(r);
+            }
+            delete ctx->c.side->prof;
+            ctx->c.side->prof = nullptr;
+        }
         int n = 0;
         for (auto& r : agg) {
             if (n >= max_rows) break;

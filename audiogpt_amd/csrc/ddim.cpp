@@ -87,11 +87,32 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
             unet.set_context(ctx, a.d_cond, nB, a.L);
     }
 
+    // Classifier-free guidance: the reference evaluates the model once on cat([x] * 2) (ddim.py:177-199); the two halves are
+    // independent until the combine, and one batch of 8 prompts leaves much of the chip idle, so the step forks
+    // after the UNet input is built -- the unconditional half on the context's stream, the conditional half on the second lane's
+    // stream and workspace -- and joins before the update kernel.  Captured, the halves are two branches of the step graph.
+    // Every kernel is batch-invariant bit for bit, so the result equals the one-stream form's.
+    const bool two_lanes = cfg && ctx.split_cfg();
+    Ctx* lane2 = two_lanes ? &side_lane(ctx) : nullptr;
+    if (lane2 && ctx.prof && !lane2->prof) {
+        lane2->prof = new Profiler;
+        lane2->prof->detail = ctx.prof->detail;
+    }
+
     // one step: identical launches on identical addresses whatever the step (the index lives on the device)
     auto step_body = [&]() {
         launch_ddim_prepare(ctx, xs, concat ? ccs : nullptr, a.B, nB, per, per_in - per, tab_t, tab_coef, d_step, xin,
                             cur_t, cur_coef, a.d_mask, a.d_x0, a.d_noise_q, a.S, emb_hoist ? emb_tab : nullptr, (int)emb_w, cur_emb);
-        unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps, emb_hoist ? cur_emb : nullptr);
+        if (lane2) {
+            MAA_HIP(hipEventRecord(ctx.ev_fork, ctx.stream));
+            MAA_HIP(hipStreamWaitEvent(lane2->stream, ctx.ev_fork, 0));
+            unet.forward(ctx, xin, cur_t, unet.context_ptr, a.B, a.H, a.W, eps, emb_hoist ? cur_emb : nullptr, 0);
+            unet.forward(*lane2, xin + (size_t)a.B * per_in, cur_t + a.B, unet.context_ptr, a.B, a.H, a.W, eps + (size_t)a.B * per,
+                         emb_hoist ? cur_emb : nullptr, a.B);
+            MAA_HIP(hipEventRecord(ctx.ev_join, lane2->stream));
+            MAA_HIP(hipStreamWaitEvent(ctx.stream, ctx.ev_join, 0));
+        } else
+            unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps, emb_hoist ? cur_emb : nullptr);
         launch_ddim_step(ctx, xin, per, per_in, eps, cfg ? eps + a.B * per : nullptr, a.scale, cur_coef, (long long)a.B * per, xs,
                          a.h_sigmas ? a.d_noise_p : nullptr, a.temperature, a.S, logging ? a.d_log_x : nullptr,
                          logging ? a.d_log_x0 : nullptr, d_step);
@@ -122,7 +143,11 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
                                      (unsigned long long)(a.h_sigmas ? 1 : 0),
                                      (unsigned long long)reinterpret_cast<uintptr_t>(ctx.stream),
                                      (unsigned long long)reinterpret_cast<uintptr_t>(ctx.ws.base()),
-                                     (unsigned long long)ctx.ws.capacity()})
+                                     (unsigned long long)ctx.ws.capacity(),
+                                     // the second lane of a CFG step: its stream and workspace are part of the captured step
+                                     (unsigned long long)reinterpret_cast<uintptr_t>(lane2 ? lane2->stream : nullptr),
+                                     (unsigned long long)reinterpret_cast<uintptr_t>(lane2 ? lane2->ws.base() : nullptr),
+                                     (unsigned long long)(lane2 ? lane2->ws.capacity() : 0)})
             k.push_back(v);
         return k;
     };

@@ -124,10 +124,23 @@ struct Tuning {
     bool no_dma = false;                    // MAA_NO_DMA: every bf16 contraction on the register-staged engine (bit-identity tests)
     bool no_halo = false;                   // MAA_NO_HALO: the narrow vocoder stages through the implicit GEMM (bit-identity test)
     bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
+    bool cfg_split = true;                  // MAA_CFG_SPLIT=0: the two halves of a classifier-free-guidance step one after the other on one stream
     void load();
 };
 
 struct Ctx {
+    Ctx() = default;
+    Ctx(const Ctx&) = delete;
+    Ctx& operator=(const Ctx&) = delete;
+    ~Ctx();
+    // Second lane of a classifier-free-guidance DDIM step (ddim.cpp): the unconditional and the conditional half of the UNet
+    // batch are independent, so the step forks after the UNet input is built -- half 0 on this context's stream, half 1 on the
+    // lane's own stream and workspace -- and joins before the combine + update kernel.  Captured, they are two branches of the
+    // step graph.  Created on first use (side_lane), owned by this context; shares the zero page, the device and the tuning.
+    Ctx* side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int cfg_split = -1;       // -1: tune.cfg_split decides; 0 / 1: maa_ctx_set_cfg_split
+    bool split_cfg() const { return cfg_split < 0 ? tune.cfg_split : cfg_split != 0; }
     Tuning tune;
     StepGraph ddim_graph;
     DevSlab sampler_scratch;  // DDIM loop state (tables, step slots, UNet input, eps): reused by every sample() call
@@ -138,6 +151,8 @@ struct Ctx {
     mutable Arena ws;    // (mutable: a launch may borrow scratch, e.g. split-K slabs, and give it back before it returns)
     int dtype = 0;   // 0 = fp32 (exact-f32 MFMA); 1 = bf16 MFMA operands, fp32 accumulate/storage
 };
+
+Ctx& side_lane(Ctx& ctx);      // the context's second lane (created on first use: stream, events)
 
 // ------------------------------------------------------------------------------------------ igemm
 // Out[m, n] = epilogue( alpha * sum_k A[m, k] * B[k, n] ),  m = (b, oy, ox) output position,

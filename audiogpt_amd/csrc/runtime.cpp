@@ -174,21 +174,56 @@ void Tuning::load() {
     no_dma = !get_s("MAA_NO_DMA").empty();
     no_halo = !get_s("MAA_NO_HALO").empty();
     snake_untiled = !get_s("MAA_SNAKE_UNTILED").empty();
+    const std::string cs = get_s("MAA_CFG_SPLIT");
+    cfg_split = cs.empty() || cs[0] != '0';
     // a stale override in an older round's format ("2,2,0,1": tile, stages ...) is refused here, when the context is created
     // (last, so that every other knob is in place), not by a check in the middle of a forward pass
-    auto check_dma2 = [](const std::string& name, std::string& v) {
+    std::string first_error;
+    auto check_dma2 = [&first_error](const std::string& name, std::string& v) {
         if (v.empty() || v == "off") return;
         int cfg = 0, ns = 4, pipe = 1, S = 1, kmin = 0, kmax = 0;
         const int k = std::sscanf(v.c_str(), "%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &kmax);
         if (k < 4 || cfg != 0 || ns != 4 || pipe != 1 || S < 1) {
             const std::string bad = v;
             v.clear();      // the context keeps running on the default policy if the caller catches the error
-            throw Error(name + "=\"" + bad + "\": expected \"off\" or \"0,4,1,S[,kmin[,kmax]]\" (the split-K engine keeps one "
-                        "instantiation: tile 0, 4 stages, pipelined; S = K slices)");
+            if (first_error.empty())
+                first_error = name + "=\"" + bad + "\": expected \"off\" or \"0,4,1,S[,kmin[,kmax]]\" (the split-K engine keeps one "
+                              "instantiation: tile 0, 4 stages, pipelined; S = K slices)";
         }
     };
+    // every override is validated (and a bad one cleared) before the first error is reported: no stale value survives a caught error
     check_dma2("MAA_DMA2", dma2);
     for (auto& kv : dma2_n) check_dma2("MAA_DMA2_N" + std::to_string(kv.first), kv.second);
+    if (!first_error.empty()) throw Error(first_error);
+}
+
+Ctx::~Ctx() {
+    if (side) {
+        (void)hipStreamSynchronize(side->stream);
+        (void)hipStreamDestroy(side->stream);
+        side->stream = nullptr;
+        delete side->prof;
+        side->prof = nullptr;
+        delete side;
+    }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+}
+Ctx& side_lane(Ctx& ctx) {
+    if (!ctx.side) {
+        hipStream_t s = nullptr;
+        MAA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        Ctx* sd = new Ctx;
+        sd->stream = s;
+        sd->device = ctx.device;
+        sd->zeros = ctx.zeros;
+        ctx.side = sd;
+        MAA_HIP(hipEventCreateWithFlags(&ctx.ev_fork, hipEventDisableTiming));
+        MAA_HIP(hipEventCreateWithFlags(&ctx.ev_join, hipEventDisableTiming));
+    }
+    ctx.side->tune = ctx.tune;
+    ctx.side->dtype = ctx.dtype;
+    return *ctx.side;
 }
 
 void StepGraph::clear() {

@@ -349,8 +349,9 @@ struct UNet::Impl {
             launch_layernorm(ctx, y1, M, inner, b.ln2g, b.ln2b, 1e-5f, ln, sp);
             float* q = ctx.ws.alloc_f((size_t)M * inner);
             linear_into(ctx, ln, inner, M, inner, b.q2, nullptr, 0, q, inner, 0, 0, sp ? M : 0);
-            MAA_CHECK(ctx.ws.dry || (kv_cache[b.kv_slot] && kv_batch == B), "set_context must precede forward (batch)");
-            const float* kv = kv_cache[b.kv_slot];
+            MAA_CHECK(ctx.ws.dry || (kv_cache[b.kv_slot] && (lane ? batch_off + B <= kv_batch : kv_batch == B)),
+                      "set_context must precede forward (batch)");
+            const float* kv = kv_cache[b.kv_slot] + (size_t)batch_off * kv_len * 2 * inner;
             attention_into(ctx, q, inner, s.dh, kv, 2 * inner, s.dh, kv + inner, 2 * inner, s.dh, B, s.heads, s.dh, HW,
                            kv_len, scale, o, inner, o_sp);
             float* y2 = ctx.ws.alloc_f((size_t)M * inner);
@@ -459,10 +460,15 @@ struct UNet::Impl {
         linear_into(ctx, semb, emb_dim, rows, emb_dim, emb_all, nullptr, 0, out, emb_all.Npad);
     }
     int emb_ld = 0;      // pitch between the samples' rows of the current forward's emb_out (0: one row for every sample)
+    // a forward over samples [batch_off, batch_off + B) of the batch set_context saw (a lane of a CFG step: ddim.cpp); the
+    // caller's x / t / out pointers already stand at that sample, the context rows and the K/V caches are offset here
+    int batch_off = 0;
+    bool lane = false;
 
     // emb_row != null: the step's ResBlock time-embedding row computed beforehand (UNet::emb_table), shared by all samples
     void forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
                  float* out_nchw, const float* emb_row = nullptr) {
+        if (context && batch_off) context += (size_t)batch_off * kv_len * cfg.context_dim;
         if (emb_row) {
             emb_ld = 0;
             forward_body(ctx, x_nchw, B, H, W, out_nchw, emb_row);
@@ -554,10 +560,20 @@ void UNet::set_context_cfg(Ctx& ctx, const float* d_uncond, const float* d_cond,
 }
 
 void UNet::forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
-                   float* out_nchw, const float* emb_row) {
+                   float* out_nchw, const float* emb_row, int batch_off) {
     Impl& m = *impl_;
     PrecisionGuard pg(ctx, m.precision);
-    run_sized(ctx, [&] { m.forward(ctx, x_nchw, t, context, B, H, W, out_nchw, emb_row); });
+    m.lane = batch_off >= 0;
+    m.batch_off = m.lane ? batch_off : 0;
+    try {
+        run_sized(ctx, [&] { m.forward(ctx, x_nchw, t, context, B, H, W, out_nchw, emb_row); });
+    } catch (...) {
+        m.batch_off = 0;
+        m.lane = false;
+        throw;
+    }
+    m.batch_off = 0;
+    m.lane = false;
 }
 int UNet::emb_width() const { return impl_->emb_all.Npad; }
 void UNet::emb_table(Ctx& ctx, const float* d_t, int rows, float* d_out) {

@@ -92,35 +92,6 @@ class MakeAnAudio:
             t.record_stream(cur)
         return out
 
-    @staticmethod
-    def generate_split(pipes, x_T, cond=None, uncond=None, scale=1.0, S=100, concat=None, use_graph=True, pool=None):
-        """ONE prompt batch as len(pipes) contiguous sub-batches, each on its own replica (stream) at the same time; the
-        results are concatenated in prompt order.  Every sample is an independent trajectory and the kernels are batch
-        invariant bit for bit (a clip alone == the clip inside its batch: tests/test_gpu_config2.py), so this returns exactly
-        what pipes[0].generate would for the whole batch -- sooner, because two half-size batches side by side fill the chip
-        better than one (profiles/r4/r4_split_probe_subbatches_on_streams.txt: 8 prompts in 885 ms instead of 953)."""
-        from concurrent.futures import ThreadPoolExecutor
-        n, m = x_T.shape[0], len(pipes)
-        bounds = [(k * n) // m for k in range(m + 1)]
-        parts = [(bounds[k], bounds[k + 1]) for k in range(m) if bounds[k + 1] > bounds[k]]
-        dev = pipes[0].device
-
-        def cut(t, lo, hi):
-            return None if t is None else t[lo:hi].contiguous()
-
-        def run(k):
-            lo, hi = parts[k]
-            torch.cuda.set_device(dev)
-            return pipes[k].generate(cut(x_T, lo, hi), cut(cond, lo, hi), cut(uncond, lo, hi), scale, S, cut(concat, lo, hi), use_graph)
-        own = pool is None
-        pool = pool or ThreadPoolExecutor(max_workers=len(parts))
-        try:
-            outs = list(pool.map(run, range(len(parts))))
-        finally:
-            if own:
-                pool.shutdown()
-        return tuple(torch.cat([o[i] for o in outs], dim=0) for i in range(3))
-
     def audio_seconds(self, n_clips, frames):
         return n_clips * frames * self.vocoder.hop / float(self.vocoder_cfg["sampling_rate"])
 

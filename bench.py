@@ -447,8 +447,9 @@ def slim_line(result, detail_path=None, limit=LINE_LIMIT):
         o["cpu_baseline"]["sample"] = str(result["cpu_baseline"].get("sample", ""))[:160]
     if result.get("one_batch_in_flight"):
         o["one_batch_in_flight"] = _pick(result["one_batch_in_flight"], ("value", "ms_per_step", "steps"))
-    if result.get("one_batch_two_streams"):
-        o["one_batch_two_streams"] = _pick(result["one_batch_two_streams"], ("value", "ms_per_step", "bit_identical_to_one_stream"))
+    for k in ("one_batch_other_form", "one_batch_two_streams"):      # (the second: records of rounds 3 / 4)
+        if result.get(k):
+            o[k] = _pick(result[k], ("value", "ms_per_step", "cfg_lanes", "bit_identical", "bit_identical_to_one_stream"))
     if result.get("box"):
         b = result["box"]
         o["box"] = _pick(b, ("sclk_mhz_median", "mclk_mhz_median", "fclk_mhz_median", "socket_power_w_median", "pci_bus_id", "class"))
@@ -850,6 +851,9 @@ def main(argv=None):
     ap.add_argument("--inflight", type=int, default=3,
                     help="prompt batches in flight per GPU: consecutive steps (independent batches of 8 prompts) run on this many "
                          "pipeline replicas / HIP streams, as a serving loop would overlap requests; 1 = strictly one after another")
+    ap.add_argument("--cfg-split", default="auto", choices=["auto", "0", "1"],
+                    help="classifier-free guidance inside the sampler: 1 = the two halves of a step as two lanes (branches of the "
+                         "captured step graph), 0 = one stream, auto = the library's default (two lanes)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="initialise the process group and issue C1 scatter / broadcast, C2 gather, the barriers and ranks_seen even "
                          "with ONE rank (RCCL exercised on the one GPU a test box has: tests/test_gpu_rccl.py)")
@@ -912,6 +916,13 @@ def main(argv=None):
         pipes = [MakeAnAudio(dev, precision=args.precision, stream=None if args.legacy_streams else torch.cuda.Stream(dev))
                  for _ in range(inflight)]
     pipe = pipes[0]
+    lanes = args.cfg_split != "0"      # (auto = the library default = two lanes unless MAA_CFG_SPLIT=0)
+    if not stub:
+        if args.cfg_split == "auto":
+            lanes = os.environ.get("MAA_CFG_SPLIT", "1")[:1] != "0"
+        else:
+            for p_ in pipes:
+                p_.ctx.set_cfg_split(lanes)
     # worker threads start with torch's thread-local device at 0: pin them to this rank's GPU (no stray context on GPU 0)
     pool = ThreadPoolExecutor(max_workers=inflight) if stub else \
         ThreadPoolExecutor(max_workers=inflight, initializer=torch.cuda.set_device, initargs=(dev,))
@@ -1042,7 +1053,7 @@ def main(argv=None):
                                "%s" % (n, S, CFG_SCALE, {"f32": "fp32 (exact-f32 MFMA)", "bf16x3": "fp32 storage, bf16x3-split MFMA (hi/lo, fp32 accumulate; meets the fp32 parity gates)", "bf16": "fp32 storage, bf16 MFMA operands"}[args.precision]),
                    "prompts_per_gpu": n, "ddim_steps": S, "latent": list(LATENT), "mel_frames": CLIP_FRAMES,
                    "audio_seconds_per_step": pipe.audio_seconds(n * world, CLIP_FRAMES), "hipgraph": use_graph,
-                   "batches_in_flight": inflight,
+                   "batches_in_flight": inflight, "cfg_lanes": 2 if lanes else 1,
                    "parallelism": "prompt-sharded x%d (RCCL bcast cond / gather wav)" % world},
         "comm_ms_per_step": {k: round(v, 4) for k, v in comm_ms.items()},
         # Little's law for the overlapped arrangement: `inflight` batches are resident for `inflight` throughput periods
@@ -1089,24 +1100,26 @@ def main(argv=None):
         result["one_batch_in_flight"] = {"value": pipe.audio_seconds(n, CLIP_FRAMES) * k1 / one, "ms_per_step": 1e3 * one / k1,
                                          "steps": k1}
         result["batch_latency_ms"]["alone"] = 1e3 * one / k1
-        if inflight >= 2 and n >= 2 and not stub:
-            # still ONE batch of n prompts in flight, run as two half-batches side by side on two replicas' streams: the same
-            # waveforms bit for bit (batch-invariant kernels), a shorter latency because two half-size launches fill the chip
-            # better than one
+        if not stub:
+            # the same batch with the two halves of every CFG step one after the other on ONE stream (the library's default runs
+            # them as two lanes -- two branches of the captured step graph, csrc/ddim.cpp): the A/B of that default, and the
+            # check that both forms give the same waveforms bit for bit
             c1, uc1 = c_all[:n], uc_row.expand(n, -1, -1).contiguous()
-            MakeAnAudio.generate_split(pipes[:2], x_T, c1, uc1, CFG_SCALE, S, use_graph=use_graph, pool=pool)      # (graphs of the half shape)
+            w_lanes = pipe.generate(x_T, c1, uc1, CFG_SCALE, S, use_graph=use_graph)[0]
+            pipe.ctx.set_cfg_split(not lanes)
+            pipe.generate(x_T, c1, uc1, CFG_SCALE, S, use_graph=use_graph)      # (captures the other form's step graph)
             barrier()
             t0 = time.perf_counter()
             for _ in range(k1):
-                w_split = MakeAnAudio.generate_split(pipes[:2], x_T, c1, uc1, CFG_SCALE, S, use_graph=use_graph, pool=pool)[0]
+                w_other = pipe.generate(x_T, c1, uc1, CFG_SCALE, S, use_graph=use_graph)[0]
             barrier()
             two = time.perf_counter() - t0
-            w_whole = pipe.generate(x_T, c1, uc1, CFG_SCALE, S, use_graph=use_graph)[0]
-            result["one_batch_two_streams"] = {
+            pipe.ctx.set_cfg_split(None if args.cfg_split == "auto" else lanes)
+            result["one_batch_other_form"] = {
                 "value": pipe.audio_seconds(n, CLIP_FRAMES) * k1 / two, "ms_per_step": 1e3 * two / k1, "steps": k1,
-                "bit_identical_to_one_stream": bool(torch.equal(w_split, w_whole)),
-                "method": "the same batch of %d prompts as two half-batches on two pipeline replicas (streams) at once" % n}
-            result["batch_latency_ms"]["alone_two_streams"] = 1e3 * two / k1
+                "cfg_lanes": 1 if lanes else 2, "bit_identical": bool(torch.equal(w_lanes, w_other)),
+                "method": "the same batch with the CFG halves of a step %s" % ("on one stream" if lanes else "as two lanes")}
+            result["batch_latency_ms"]["alone_other_form"] = 1e3 * two / k1
     if rank == 0 and world == 1 and not args.no_secondary:
         for p_ in pipes:
             p_.close()

@@ -59,8 +59,15 @@ int maa_ctx_set_stream(maa_ctx* ctx, void* hip_stream);
  *   2  bf16: operands rounded to bf16, fp32 accumulation (throughput mode, error reported not gated)
  * Storage, normalisations, softmax and every epilogue stay fp32 in all modes. */
 int maa_ctx_set_precision(maa_ctx* ctx, int mode);
+/* Classifier-free guidance inside maa_ddim_sample (ddim.py:177-199 evaluates the model on cat([x] * 2) in one call): the
+ * unconditional and the conditional half of that batch are independent trajectories until the combine, and the library runs
+ * them as two lanes -- two branches of the captured step graph, each half on its own stream and workspace -- because one batch
+ * of 8 prompts leaves much of the chip idle.  Bit-identical to the one-stream form (every kernel is batch-invariant).
+ *   1 two lanes, 0 one stream, -1 the default policy (two lanes unless MAA_CFG_SPLIT=0).
+ * A server that already keeps several independent batches in flight on several contexts may prefer 0. */
+int maa_ctx_set_cfg_split(maa_ctx* ctx, int mode);
 /* The tuning / test knobs of the environment (MAA_PP, MAA_PP1, MAA_DMA2, MAA_DMA2_N<n>, MAA_DMA2_PERSIST, MAA_PP_DBG,
- * MAA_OP_PRESPLIT, MAA_DMA_NS_LOW, MAA_NO_DMA, MAA_NO_HALO, MAA_SNAKE_UNTILED) are
+ * MAA_OP_PRESPLIT, MAA_DMA_NS_LOW, MAA_NO_DMA, MAA_NO_HALO, MAA_SNAKE_UNTILED, MAA_CFG_SPLIT) are
  * parsed in one place, when a context is created; this parses them again (and drops the step graph the sampler keeps).  A
  * malformed MAA_DMA2 / MAA_DMA2_N<n> value fails here (and in maa_ctx_create) with a message naming the variable.  For tests
  * and A/B runs. */

@@ -216,3 +216,37 @@ def _ddim_variant(ctx, golden, name, cfg, ldm, seed, tol, tag=""):
                                                ("ddim_inpaint_s4", C.UNET_INPAINT, C.LDM_INPAINT, 5)])
 def test_ddim_variants_match_reference(golden, ctx, name, cfg, ldm, seed):
     _ddim_variant(ctx, golden, name, cfg, ldm, seed, 1e-4)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_cfg_halves_as_two_lanes_are_bit_identical_to_one_stream(golden, precision):
+    """csrc/ddim.cpp runs the unconditional and the conditional half of a classifier-free-guidance step (ddim.py:177-199: one
+    model call on cat([x] * 2)) as two lanes -- two branches of the captured step graph, the second on its own stream and
+    workspace.  Every kernel is batch-invariant, so the latents must equal the one-stream form's bit for bit: T2A (77-token
+    context, scale 1.5) and the image-to-audio UNet (1-token context added to the time embedding, scale 3), graph and eager, a
+    second call on the kept graph, and a batch of one."""
+    from audiogpt_amd.backend import Context, UNet
+    c = Context("cuda:0", precision=precision)
+    try:
+        for name, cfg, ldm, seed in (("ddim_t2a_s10", C.UNET_T2A, C.LDM_T2A, 0), ("ddim_i2a_s4", C.UNET_I2A, C.LDM_I2A, 4)):
+            g = golden(name)
+            u = UNet(c, cfg, WT.make_unet_state_dict(cfg, seed=seed))
+            steps, a, ap = _ddim_tables(4, ldm)
+            x = torch.from_numpy(g["x_T"])
+            kw = dict(cond=torch.from_numpy(g["c"]), uncond=torch.from_numpy(g["uc"]), scale=float(g["scale"]))
+            out = {}
+            for lanes in (True, False):
+                c.set_cfg_split(lanes)
+                out[lanes, "eager"] = u.ddim_sample(x, steps, a, ap, use_graph=False, **kw).cpu()
+                out[lanes, "graph"] = u.ddim_sample(x, steps, a, ap, use_graph=True, **kw).cpu()
+                out[lanes, "again"] = u.ddim_sample(x, steps, a, ap, use_graph=True, **kw).cpu()
+                one = u.ddim_sample(x[:1], steps, a, ap, use_graph=True, cond=kw["cond"][:1], uncond=kw["uncond"][:1], scale=kw["scale"]).cpu()
+                assert torch.equal(one, out[lanes, "graph"][:1]), (name, lanes)
+            ref = out[False, "eager"]
+            assert float(ref.abs().max()) > 0 and bool(torch.isfinite(ref).all())
+            for k, v in out.items():
+                assert torch.equal(v, ref), (name, k)
+            u.close()
+        c.set_cfg_split(None)
+    finally:
+        c.close()

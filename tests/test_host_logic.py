@@ -454,7 +454,7 @@ def test_bench_stdout_line_fits_the_drivers_capture(capsys):
     assert len(line) <= bench.LINE_LIMIT == 6144 and "\n" not in line
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "one_batch_in_flight", "one_batch_two_streams", "box"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "one_batch_in_flight", "one_batch_two_streams", "box"):      # (round 4 record: the two-stream experiment of that round)
         assert k in d, k
     assert d["value"] == pytest.approx(full["value"], rel=1e-6) and d["config"]["batches_in_flight"] == 3
     assert d["one_batch_in_flight"]["value"] == pytest.approx(full["one_batch_in_flight"]["value"], rel=1e-4)
