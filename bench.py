@@ -446,7 +446,7 @@ def slim_line(result, detail_path=None, limit=LINE_LIMIT):
         o["cpu_baseline"] = _pick(result["cpu_baseline"], _CPU_KEEP)
         o["cpu_baseline"]["sample"] = str(result["cpu_baseline"].get("sample", ""))[:160]
     if result.get("one_batch_in_flight"):
-        o["one_batch_in_flight"] = _pick(result["one_batch_in_flight"], ("value", "ms_per_step", "steps"))
+        o["one_batch_in_flight"] = _pick(result["one_batch_in_flight"], ("value", "ms_per_step", "steps", "cfg_lanes"))
     for k in ("one_batch_other_form", "one_batch_two_streams"):      # (the second: records of rounds 3 / 4)
         if result.get(k):
             o[k] = _pick(result[k], ("value", "ms_per_step", "cfg_lanes", "bit_identical", "bit_identical_to_one_stream"))
@@ -669,6 +669,8 @@ def run_t2a_variant(dev, precision, vocoder_cfg, label, cpu_parts=None, steps=6,
     from audiogpt_amd.pipeline import MakeAnAudio
     n, S = PROMPTS_PER_GPU, DDIM_STEPS
     pipes = [MakeAnAudio(dev, vocoder_cfg=vocoder_cfg, precision=precision, stream=torch.cuda.Stream(dev)) for _ in range(inflight)]
+    for p_ in pipes:
+        p_.ctx.set_cfg_split(inflight == 1)      # (as the headline: lanes only when one batch owns the GPU)
     x_T, c, uc = _t2a_inputs(n, dev)
     pool = ThreadPoolExecutor(max_workers=inflight, initializer=torch.cuda.set_device, initargs=(dev,))
     gen = lambda p_: p_.generate(x_T, c, uc, CFG_SCALE, S)      # noqa: E731
@@ -679,7 +681,10 @@ def run_t2a_variant(dev, precision, vocoder_cfg, label, cpu_parts=None, steps=6,
     round_of(inflight)        # warm-up: every replica sizes its workspace and captures its step graph
     per_step, _ = _timed(lambda: round_of(steps), 1)
     per_step /= steps
+    pipes[0].ctx.set_cfg_split(True)
+    gen(pipes[0])                                  # (the step graph of the two-lane form)
     one, (wav, spec, z) = _timed(lambda: gen(pipes[0]), 2)
+    pipes[0].ctx.set_cfg_split(inflight == 1)
     audio_s = pipes[0].audio_seconds(n, CLIP_FRAMES)
     res = {"metric": "generated audio-seconds/sec (10s clip, 100 DDIM steps) [%d independent batches of %d prompts in flight]" % (inflight, n),
            "value": audio_s / per_step, "unit": "audio-seconds/sec", "n_gpus": 1, "steps": steps, "warmup": 1,
@@ -916,13 +921,15 @@ def main(argv=None):
         pipes = [MakeAnAudio(dev, precision=args.precision, stream=None if args.legacy_streams else torch.cuda.Stream(dev))
                  for _ in range(inflight)]
     pipe = pipes[0]
-    lanes = args.cfg_split != "0"      # (auto = the library default = two lanes unless MAA_CFG_SPLIT=0)
+    # CFG halves of a DDIM step as two lanes (the library's default; csrc/ddim.cpp): worth +4 % when ONE batch owns the GPU, but
+    # with three batches in flight the chip is already full from outside and six concurrent lanes lose 24 % (profiles/
+    # r5_call1_cfg_lanes_ab.txt) -- so the replicas of the overlapped arrangement run their steps on one stream each, as a
+    # server that overlaps requests would configure them, and `one_batch_in_flight` runs with the lanes
+    lanes = args.cfg_split == "1" or (args.cfg_split == "auto" and inflight == 1)
+    lanes_one = args.cfg_split != "0"
     if not stub:
-        if args.cfg_split == "auto":
-            lanes = os.environ.get("MAA_CFG_SPLIT", "1")[:1] != "0"
-        else:
-            for p_ in pipes:
-                p_.ctx.set_cfg_split(lanes)
+        for p_ in pipes:
+            p_.ctx.set_cfg_split(lanes)
     # worker threads start with torch's thread-local device at 0: pin them to this rank's GPU (no stray context on GPU 0)
     pool = ThreadPoolExecutor(max_workers=inflight) if stub else \
         ThreadPoolExecutor(max_workers=inflight, initializer=torch.cuda.set_device, initargs=(dev,))
@@ -1091,6 +1098,9 @@ def main(argv=None):
     if rank == 0 and world == 1 and inflight > 1 and args.steps >= 2:
         # the same K steps strictly one batch after another on one stream (the latency-oriented number)
         k1 = min(args.steps, 3)
+        if not stub:
+            pipe.ctx.set_cfg_split(lanes_one)
+            pipe.generate(x_T, c_all[:n], uc_row.expand(n, -1, -1).contiguous(), CFG_SCALE, S, use_graph=use_graph)      # (its step graph)
         barrier()
         t0 = time.perf_counter()
         for _ in range(k1):
@@ -1098,7 +1108,7 @@ def main(argv=None):
         barrier()
         one = time.perf_counter() - t0
         result["one_batch_in_flight"] = {"value": pipe.audio_seconds(n, CLIP_FRAMES) * k1 / one, "ms_per_step": 1e3 * one / k1,
-                                         "steps": k1}
+                                         "steps": k1, "cfg_lanes": 2 if lanes_one else 1}
         result["batch_latency_ms"]["alone"] = 1e3 * one / k1
         if not stub:
             # the same batch with the two halves of every CFG step one after the other on ONE stream (the library's default runs
@@ -1106,7 +1116,7 @@ def main(argv=None):
             # check that both forms give the same waveforms bit for bit
             c1, uc1 = c_all[:n], uc_row.expand(n, -1, -1).contiguous()
             w_lanes = pipe.generate(x_T, c1, uc1, CFG_SCALE, S, use_graph=use_graph)[0]
-            pipe.ctx.set_cfg_split(not lanes)
+            pipe.ctx.set_cfg_split(not lanes_one)
             pipe.generate(x_T, c1, uc1, CFG_SCALE, S, use_graph=use_graph)      # (captures the other form's step graph)
             barrier()
             t0 = time.perf_counter()
@@ -1114,11 +1124,11 @@ def main(argv=None):
                 w_other = pipe.generate(x_T, c1, uc1, CFG_SCALE, S, use_graph=use_graph)[0]
             barrier()
             two = time.perf_counter() - t0
-            pipe.ctx.set_cfg_split(None if args.cfg_split == "auto" else lanes)
+            pipe.ctx.set_cfg_split(lanes)
             result["one_batch_other_form"] = {
                 "value": pipe.audio_seconds(n, CLIP_FRAMES) * k1 / two, "ms_per_step": 1e3 * two / k1, "steps": k1,
-                "cfg_lanes": 1 if lanes else 2, "bit_identical": bool(torch.equal(w_lanes, w_other)),
-                "method": "the same batch with the CFG halves of a step %s" % ("on one stream" if lanes else "as two lanes")}
+                "cfg_lanes": 1 if lanes_one else 2, "bit_identical": bool(torch.equal(w_lanes, w_other)),
+                "method": "the same batch with the CFG halves of a step %s" % ("on one stream" if lanes_one else "as two lanes")}
             result["batch_latency_ms"]["alone_other_form"] = 1e3 * two / k1
     if rank == 0 and world == 1 and not args.no_secondary:
         for p_ in pipes:
