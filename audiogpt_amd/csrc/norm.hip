@@ -159,6 +159,160 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
 }
 
+
+// GroupNorm in ONE pass over the data (round 5): a workgroup owns GPB consecutive groups of one sample -- CB = GPB cpg channels,
+// a run of CB * 4 contiguous bytes per position -- and keeps all of that sample's rows of them in registers: thread (row lane ty,
+// float4 column tx) loads rows ty, ty + RL, ... (NR float4s, all in flight together), the statistics are reduced through LDS in a
+// fixed order, and the normalised (+ SiLU) rows are written from the registers -- fp32 or split32, plus the optional raw split32
+// copy -- so the tensor is read once and the statistics launch, its table and the dependent second launch are gone (two launches
+// of 10 + 8 us per GroupNorm at the UNet's sizes, both latency-bound: DESIGN.md 3.4).  Same arithmetic as the two-pass kernels:
+// sums of d = x - pivot and d^2 with the group's first element as pivot, scale = gamma rstd, shift = beta - mean scale,
+// y = x scale + shift.  The layout (GPB, RL, NR) is a function of (C, HW) only and a workgroup sees one sample: a sample's result
+// does not depend on its batch.
+template <int NR>
+__global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict__ x1, int ld1, int C1,
+                                                        const float* __restrict__ x2, int ld2, int C2, int HW, int groups,
+                                                        int GPB, float eps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int silu, float* __restrict__ out,
+                                                        int split, float* __restrict__ raw_split) {
+    extern __shared__ float gsm[];      // red[RL Q 8] | colsum[2 CB] | gstat[2 GPB]
+    const int C = C1 + C2, cpg = C / groups, CB = GPB * cpg, Q = CB >> 2;
+    const int RL = (int)blockDim.x / Q;                      // (blockDim.x == RL Q)
+    const int b = blockIdx.y, c_lo = blockIdx.x * CB;
+    const int t = threadIdx.x, ty = t / Q, tx = t - ty * Q;
+    const int c = c_lo + 4 * tx;
+    float* const red = gsm;
+    float* const colsum = gsm + (size_t)RL * Q * 8;
+    float* const gstat = colsum + 2 * CB;
+    const float* src;
+    long long ld;
+    if (c < C1) {
+        src = x1 + (long long)b * HW * ld1 + c;
+        ld = ld1;
+    } else {
+        src = x2 + (long long)b * HW * ld2 + (c - C1);
+        ld = ld2;
+    }
+    // pivot of each of the float4's four channels = first element of that channel's group
+    int gl[4];
+    float piv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        gl[j] = (4 * tx + j) / cpg;
+        const int c0 = c_lo + gl[j] * cpg;
+        piv[j] = c0 < C1 ? x1[(long long)b * HW * ld1 + c0] : x2[(long long)b * HW * ld2 + (c0 - C1)];
+    }
+    float4 v[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int r = ty + RL * k;
+        v[k] = r < HW ? *reinterpret_cast<const float4*>(src + (long long)r * ld) : make_float4(piv[0], piv[1], piv[2], piv[3]);
+    }
+    float sd[4] = {0.f, 0.f, 0.f, 0.f}, qd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const float d0 = v[k].x - piv[0], d1 = v[k].y - piv[1], d2 = v[k].z - piv[2], d3 = v[k].w - piv[3];
+        sd[0] += d0;
+        sd[1] += d1;
+        sd[2] += d2;
+        sd[3] += d3;
+        qd[0] += d0 * d0;
+        qd[1] += d1 * d1;
+        qd[2] += d2 * d2;
+        qd[3] += d3 * d3;
+    }
+    {
+        float4* r4 = reinterpret_cast<float4*>(red + (size_t)t * 8);
+        r4[0] = make_float4(sd[0], sd[1], sd[2], sd[3]);
+        r4[1] = make_float4(qd[0], qd[1], qd[2], qd[3]);
+    }
+    __syncthreads();
+    // per channel and statistic: the RL row lanes' partials, four interleaved chains in a fixed order
+    if (t < 2 * CB) {
+        const int stat = t / CB, cc = t - stat * CB;
+        const float* p0 = red + (size_t)(cc >> 2) * 8 + stat * 4 + (cc & 3);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int y = 0;
+        for (; y + 3 < RL; y += 4) {
+            a0 += p0[(size_t)(y + 0) * Q * 8];
+            a1 += p0[(size_t)(y + 1) * Q * 8];
+            a2 += p0[(size_t)(y + 2) * Q * 8];
+            a3 += p0[(size_t)(y + 3) * Q * 8];
+        }
+        for (; y < RL; ++y) a0 += p0[(size_t)y * Q * 8];
+        colsum[t] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (t < GPB) {
+        float s = 0.f, q = 0.f;
+        for (int i = 0; i < cpg; ++i) {
+            s += colsum[t * cpg + i];
+            q += colsum[CB + t * cpg + i];
+        }
+        const int c0 = c_lo + t * cpg;
+        const float pv = c0 < C1 ? x1[(long long)b * HW * ld1 + c0] : x2[(long long)b * HW * ld2 + (c0 - C1)];
+        const float n = (float)HW * (float)cpg;
+        const float sm = s / n, qm = q / n;
+        const float var = fmaxf(qm - sm * sm, 0.f);
+        gstat[2 * t] = pv + sm;
+        gstat[2 * t + 1] = 1.f / sqrtf(var + eps);
+    }
+    __syncthreads();
+    float sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sc[j] = gamma[c + j] * gstat[2 * gl[j] + 1];
+        sh[j] = beta[c + j] - gstat[2 * gl[j]] * sc[j];
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const int r = ty + RL * k;
+        if (r < HW) {
+            const long long row = (long long)b * HW + r;
+            float4 y;
+            y.x = v[k].x * sc[0] + sh[0];
+            y.y = v[k].y * sc[1] + sh[1];
+            y.z = v[k].z * sc[2] + sh[2];
+            y.w = v[k].w * sc[3] + sh[3];
+            if (silu) {
+                y.x = __fdividef(y.x, 1.f + __expf(-y.x));
+                y.y = __fdividef(y.y, 1.f + __expf(-y.y));
+                y.z = __fdividef(y.z, 1.f + __expf(-y.z));
+                y.w = __fdividef(y.w, 1.f + __expf(-y.w));
+            }
+            store4(out, row, c, C, split, y);
+            if (raw_split) store4(raw_split, row, c, C, 1, v[k]);
+        }
+    }
+}
+
+// Layout of the one-pass GroupNorm for a tensor of C channels x HW positions per sample, or gpb = 0 when a sample's rows of
+// even one group block do not fit the registers of a workgroup (the VAE's large images: the two-pass kernels stay).  A function
+// of (C, HW, groups) only.
+struct GnFusedPlan {
+    int gpb = 0, nr = 0, threads = 0;
+    size_t lds = 0;
+};
+GnFusedPlan gn_fused_plan(int C, int C1, int HW, int groups) {
+    GnFusedPlan pl;
+    const int cpg = C / groups;
+    for (int gpb : {4, 2, 8, 1, 16}) {
+        if (groups % gpb) continue;
+        const int CB = gpb * cpg;
+        if (CB % 4 || CB > 512) continue;
+        const int Q = CB / 4, RL = 1024 / Q;
+        if (RL < 1) continue;
+        const int need = (HW + RL - 1) / RL;
+        if (need > 16) continue;
+        pl.gpb = gpb;
+        pl.nr = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
+        pl.threads = RL * Q;
+        pl.lds = ((size_t)RL * Q * 8 + 2 * CB + 2 * gpb) * sizeof(float);
+        return pl;
+    }
+    return pl;
+}
+
 // LayerNorm: one wave per row, four channels per lane per step, row cached in registers (C <= 256*NR)
 template <int NR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long rows, int C,
@@ -317,6 +471,23 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
     MAA_CHECK(C % groups == 0 && C / groups <= 256 && C % 4 == 0 && C1 % 4 == 0 && ld1 % 4 == 0 && (C2 == 0 || ld2 % 4 == 0),
               "groupnorm channels");
     ProfScope prof(ctx, "groupnorm", 0.0, 8.0 * B * (double)HW * C);
+    const GnFusedPlan fp = ctx.tune.gn_two_pass ? GnFusedPlan() : gn_fused_plan(C, C1, HW, groups);
+    if (fp.gpb) {
+        dim3 grid((unsigned)(groups / fp.gpb), (unsigned)B);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid, dim3((unsigned)fp.threads), fp.lds, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW, groups, fp.gpb, eps,
+                               gamma, beta, silu, out, out_split, raw_split);
+        };
+        switch (fp.nr) {
+            case 1: go(gn_fused_kernel<1>); break;
+            case 2: go(gn_fused_kernel<2>); break;
+            case 4: go(gn_fused_kernel<4>); break;
+            case 8: go(gn_fused_kernel<8>); break;
+            default: go(gn_fused_kernel<16>); break;
+        }
+        MAA_HIP(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW, groups,
                        eps, gamma, beta, tab);
     const int rb = (HW + 15) / 16, passes = (C / 4 + 15) / 16;
