@@ -125,7 +125,6 @@ int maa_ctx_create(int device_id, void* hip_stream, maa_ctx** out) {
         }
         c->c.zeros = static_cast<float*>(z);
         try {
-            maa::ctx_device_buffers(c->c);
             c->c.tune.load();
         } catch (...) {      // a malformed override: nothing of the half-built context survives the error
             (void)hipFree(z);

@@ -76,8 +76,6 @@ struct PPArgs {
     int nci, cps;        // channel chunks in all, per K slice
     int Nb;              // rows of the packed weight that exist
     float* part;         // split-K slabs or null
-    int S;               // K slices
-    int* sync;           // OUT = 3: the context's arrival words, two per tile (ticket, slabs complete), zero between launches
     int dbg;             // TUNE instantiation only (MAA_PP_DBG): 1 no MFMAs, 2 no copies after the prologue, 4 no fragment reads, 8 no vmcnt wait
 };
 
@@ -87,13 +85,8 @@ struct PPArgs {
 // PERSIST = false: a launch whose grid covers every item (the UNet's: 196-208 items on 256 CUs) -- the epilogue does not carry
 // the next item's staging state, which is what made the 256 x 160 instantiation spill 81 VGPRs
 // OUT: 0 = the result leaves through the fused epilogue or as a split-K slab (run-time choice; the TUNE build), 1 = epilogue
-// only, 2 = slab only (the reduce launch finishes: rounds 3 / 4, kept behind MAA_PP_REDUCE=1 for A/B and bit-identity tests),
-// 3 = split-K finished IN the kernel (round 5, the UNet's launches): the K slices of a tile take a ticket as they leave the K
-// loop; all but the last to arrive publish their accumulators as a slab (write-through stores) and count themselves done; the
-// last one waits for that count -- only for workgroups that are already past their K loop, a few microseconds of stores, so
-// nothing depends on dispatch order or residency -- adds the S - 1 slabs to its own registers IN SLICE ORDER
-// ((s0 + s1) + s2) + s3 whichever slice it is (bit-identical to the reduce launch) and runs the fused epilogue.  One slab write
-// and one slab read per tile fewer than the reduce launch, and no second launch.
+// only, 2 = slab only -- the UNet's launches are all of the last kind, and an instantiation without the epilogue's registers
+// has no scratch at all
 template <int MI, int NI, int GWM, int GWN, int NPA, bool TUNE, bool PERSIST, int OUT>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPArgs q) {
     constexpr int BN = GWN * NI * 32;
@@ -109,7 +102,6 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     char* const sB = smem + a_bytes;
     char* const sZ = sB + NSB * BN * 128;
     char* const sD = sZ + 128;
-    int* const sT = reinterpret_cast<int*>(sD + 1024);      // (OUT = 3) the workgroup's ticket, broadcast to its waves
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -134,7 +126,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     const int TAPS = q.T;
     const int W = q.W, H = q.H;
     const long long Mtot = p.M;
-    int item = 0, m0 = 0, n0 = 0, c_begin = 0, c_end = 0, NQ = 0, cur_slice = 0, cur_tile = 0;
+    int item = 0, m0 = 0, n0 = 0, c_begin = 0, c_end = 0, NQ = 0;
 
     // zero line (read by lanes whose tap is outside the image)
     if (tid < 8) *reinterpret_cast<f32x4*>(sZ + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -174,11 +166,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     auto setup_item = [&](int w) __attribute__((always_inline)) {
         item = w_lo + w;
         // (the quotients are wave-uniform but come out of the VALU's division sequence: back into SGPRs)
-        // OUT = 3: the slices of a tile are neighbours in the item order (same XCD, leaving their K loops together)
-        const int slice = __builtin_amdgcn_readfirstlane(OUT == 3 ? item % q.S : item / q.tiles);
-        const int tile = __builtin_amdgcn_readfirstlane(OUT == 3 ? item / q.S : item - slice * q.tiles);
-        cur_slice = slice;
-        cur_tile = tile;
+        const int slice = __builtin_amdgcn_readfirstlane(item / q.tiles), tile = item - slice * q.tiles;
         const int mt = __builtin_amdgcn_readfirstlane(tile / q.ntiles), nt = tile - mt * q.ntiles;
         m0 = mt * BM;
         n0 = nt * BN;
@@ -386,7 +374,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         }
         // Every fragment read of this item is done (a wave gets here through the barrier that follows group 1's last memory
         // phase): the next item's first copies may overwrite the rings while this item's results are stored.
-        const int e_item = item, e_m0 = m0, e_n0 = n0, e_slice = cur_slice, e_tile = cur_tile;
+        const int e_item = item, e_m0 = m0, e_n0 = n0;
         const int w_next = w_cur + w_step;
         bool more = false;
         if constexpr (PERSIST) {
@@ -402,147 +390,6 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         const int row_base = e_m0 + grp * 128 + wm * (32 * MI), col_base = e_n0 + wn * (32 * NI);
         if (OUT == 1 || (OUT == 0 && q.part == nullptr)) {
             igemm_epilogue<MI, NI>(p, acc, row_base, col_base, lrow, lk, 0, q.Nb, rpb);
-        } else if constexpr (OUT == 3) {
-            // ---- split-K finished in the kernel (see OUT above).  Slab of (slice, tile): [MI NI blocks][4 quads][512 threads][4]
-            constexpr int NBLK = MI * NI;
-            const long long slab_f = (long long)(NBLK * 4) * 512 * 4;      // floats per slab
-            int* const words = q.sync + 2 * e_tile;
-            if (tid == 0) sT[0] = __hip_atomic_fetch_add(words, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const int ticket = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(sT));
-            if (ticket != q.S - 1) {
-                float* pp = q.part + ((long long)e_slice * q.tiles + e_tile) * slab_f + (long long)tid * 4;
-#pragma unroll
-                for (int b = 0; b < NBLK; ++b)
-#pragma unroll
-                    for (int qd = 0; qd < 4; ++qd) {
-                        const f32x4 v = {acc[b / NI][b % NI][4 * qd], acc[b / NI][b % NI][4 * qd + 1], acc[b / NI][b % NI][4 * qd + 2],
-                                         acc[b / NI][b % NI][4 * qd + 3]};
-                        // write-through (sc0 sc1): the reader may sit on another XCD, whose L2 does not see this one's dirty lines
-                        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(pp + (long long)(b * 4 + qd) * 512 * 4), "v"(v) : "memory");
-                    }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();      // every wave's stores have left before the slab is counted complete
-                if (tid == 0) __hip_atomic_fetch_add(words + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                if (tid == 0) {
-                    // the other slices are past their K loops (they hold tickets): at most a slab's worth of stores to wait for
-                    const long long t0 = (long long)__builtin_readcyclecounter();
-                    while (__hip_atomic_load(words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != q.S - 1) {
-                        __builtin_amdgcn_s_sleep(4);
-                        if ((long long)__builtin_readcyclecounter() - t0 > (1ll << 31)) __builtin_trap();      // (~1 s: never in a healthy run)
-                    }
-                    __hip_atomic_store(words, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // zero again for the next launch
-                    __hip_atomic_store(words + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __syncthreads();
-                // x_0 + x_1 + ... in slice order, x_s = this workgroup's registers for s = its own slice, else slab s.  Two 32x32
-                // blocks at a time: the loads of all S - 1 slabs AND of the epilogue's operands (bias, time-embedding row, residual)
-                // go out together -- one memory round trip per group -- then the sums, the epilogue arithmetic and the stores.
-                // The epilogue here is the lean form the host has checked the problem for (pp_lean_epilogue: bias, per-sample
-                // row add, residual, fp32 column-pair stores -- every 3x3 convolution of the UNet); same expressions in the same
-                // order as igemm_epilogue.h, so the result equals the reduce launch's bit for bit.
-                const float* const base = q.part + (long long)e_tile * slab_f + (long long)tid * 4;
-                const long long sstride = (long long)q.tiles * slab_f;
-                const int bmax = (p.M - 1) / rpb;
-                constexpr int G = 2;
-                static_for<0, (NBLK + G - 1) / G>([&](auto gc) {
-                    constexpr int b0 = decltype(gc)::value * G;
-                    constexpr int nb = NBLK - b0 < G ? NBLK - b0 : G;
-                    f32x4 L[3][nb][4];
-                    float bias[nb], ra0[nb], ra1[nb], rs[nb][16];
-#pragma unroll
-                    for (int t = 0; t < 3; ++t)
-                        if (t < q.S - 1) {
-                            const int s = t + (t >= e_slice ? 1 : 0);      // slabs in slice order, this workgroup's own skipped
-                            const float* sp = base + (long long)s * sstride;
-#pragma unroll
-                            for (int b = 0; b < nb; ++b)
-#pragma unroll
-                                for (int qd = 0; qd < 4; ++qd)
-                                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1"
-                                                 : "=v"(L[t][b][qd])
-                                                 : "v"(sp + (long long)((b0 + b) * 4 + qd) * 512 * 4)
-                                                 : "memory");
-                        }
-#pragma unroll
-                    for (int b = 0; b < nb; ++b) {
-                        const int bi = (b0 + b) / NI, bj = (b0 + b) % NI;
-                        const int n = col_base + bj * 32 + lrow, nc = min(n, p.N - 1);
-                        const int mb = row_base + bi * 32;
-                        const int bs = mb / rpb;
-                        bias[b] = p.bias ? p.bias[nc] : 0.f;
-                        ra0[b] = ra1[b] = 0.f;
-                        if (p.rowadd) {
-                            ra0[b] = p.rowadd[(long long)min(bs, bmax) * p.ld_rowadd + nc];
-                            ra1[b] = p.rowadd[(long long)min(bs + 1, bmax) * p.ld_rowadd + nc];
-                        }
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int m = min(mb + (r & 3) + 8 * (r >> 2) + 4 * lk, p.M - 1);
-                            rs[b][r] = p.res ? p.res[(long long)m * p.ldr + nc] : 0.f;
-                        }
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int t = 0; t < 3; ++t)
-                        if (t < q.S - 1) {
-#pragma unroll
-                            for (int b = 0; b < nb; ++b)
-#pragma unroll
-                                for (int qd = 0; qd < 4; ++qd) asm volatile("" : "+v"(L[t][b][qd]));      // (read only after the wait)
-                        }
-#pragma unroll
-                    for (int b = 0; b < nb; ++b) {
-                        const int bi = (b0 + b) / NI, bj = (b0 + b) % NI;
-                        float outv[16];
-#pragma unroll
-                        for (int qd = 0; qd < 4; ++qd) {
-                            const f32x4 own = {acc[bi][bj][4 * qd], acc[bi][bj][4 * qd + 1], acc[bi][bj][4 * qd + 2], acc[bi][bj][4 * qd + 3]};
-                            f32x4 r = e_slice == 0 ? own : L[0][b][qd];
-                            if (e_slice == 0) r += L[0][b][qd];
-#pragma unroll
-                            for (int t = 1; t < 3; ++t)
-                                if (t < q.S - 1) {
-                                    if (t == e_slice) r += own;
-                                    r += L[t][b][qd];
-                                }
-                            if (e_slice == q.S - 1) r += own;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) outv[4 * qd + e] = r[e];
-                        }
-                        const int n = col_base + bj * 32 + lrow;
-                        const int mb = row_base + bi * 32;
-                        const int nextb = (mb / rpb + 1) * rpb;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int m = min(mb + (r & 3) + 8 * (r >> 2) + 4 * lk, p.M - 1);
-                            float v = outv[r] * p.alpha + bias[b];
-                            if (p.rowadd) v += m < nextb ? ra0[b] : ra1[b];
-                            if (p.res) v += rs[b][r];
-                            outv[r] = v;
-                        }
-                        // fp32 rows, two columns per lane (igemm_epilogue.h, PAIR): the lanes of an even / odd column pair swap one
-                        // value per pair of rows, the even lane stores columns (n, n + 1) of the even row, the odd lane the odd row's
-                        if (n < p.N) {
-                            const bool even = (lrow & 1) == 0;
-#pragma unroll
-                            for (int rp = 0; rp < 8; ++rp) {
-                                const float keep = even ? outv[2 * rp] : outv[2 * rp + 1];
-                                const float give = even ? outv[2 * rp + 1] : outv[2 * rp];
-                                const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, false));
-                                const int r = 2 * rp + (even ? 0 : 1);
-                                const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                                if (m < p.M) {
-                                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                                    const f32x2 v2 = even ? f32x2{keep, got} : f32x2{got, keep};
-                                    *reinterpret_cast<f32x2*>(p.c + (long long)m * p.ldc + (n & ~1)) = v2;
-                                }
-                            }
-                        }
-                    }
-                });
-            }
         } else {
             // slab of this (slice, tile): [MI NI blocks][4 register quads][512 threads][4 floats]
             float* pp = q.part + ((long long)e_item * (MI * NI * 4) * 512 + tid) * 4;
@@ -587,7 +434,7 @@ PPGeom pp_geom(const IGemm& p) {
 // issued during tap t = pa / (8 npa) and lands on the current chunk's lines NLp + 8 pa - CAP .. + 7, which must lie below the
 // first line tap t = (ky, kx) and every later tap read, ky rowstep + kx colstep (the tap offsets ascend with t).
 int pp_ring_lines(const PPGeom& g, int bn) {
-    const int room = (163840 - 1280 - NSB * bn * 128) / 128 / 16 * 16;      // (zero line, dump, the ticket word)
+    const int room = (163840 - 1152 - NSB * bn * 128) / 128 / 16 * 16;
     if (room >= 2 * g.NLp) return 2 * g.NLp;
     int X = 0;
     for (int pa = 0; pa < g.NLp / 8; ++pa) {
@@ -598,13 +445,6 @@ int pp_ring_lines(const PPGeom& g, int bn) {
     }
     const int cap = g.NLp + (X + 15) / 16 * 16;
     return cap <= room ? cap : 0;
-}
-
-// What the in-kernel finish's epilogue covers (everything the UNet's 3x3 convolutions ask for): bias, the per-sample
-// time-embedding row, a residual, plain fp32 output whose columns pair up; anything else keeps the reduce launch.
-bool pp_lean_epilogue(const IGemm& p) {
-    return !p.geglu && p.act == 0 && p.out_scale == 1.f && !p.accumulate && !p.c_split && p.c2 == nullptr && !p.no_pair && p.Z == 1 &&
-           (p.N & 1) == 0 && (p.ldc & 1) == 0 && (reinterpret_cast<uintptr_t>(p.c) & 7) == 0 && (!p.rowadd || p.Hout * p.Wout >= 32);
 }
 
 template <int MI, int NI, int GWM, int GWN, int NPA>
@@ -620,10 +460,7 @@ void launch_npa(const Ctx& ctx, const IGemm& p, const PPArgs& q, int items, size
         hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
     };
     const bool persist = q.items > items, slab = q.part != nullptr;      // (more items than workgroups: persistent)
-    const bool finish = slab && q.sync != nullptr;                         // K slices finished in the kernel (OUT = 3)
-    if (persist && finish) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 3>);
-    else if (finish) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, false, 3>);
-    else if (persist && slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 2>);
+    if (persist && slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 2>);
     else if (persist) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 1>);
     else if (slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, false, 2>);
     else go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, false, 1>);
@@ -655,16 +492,10 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     q.cps = (q.nci + pl.S - 1) / pl.S;
     q.Nb = Nb;
     q.part = pl.S > 1 ? part : nullptr;
-    q.S = pl.S;
-    // K slices finished in the kernel by the last one to arrive (needs the context's arrival words; MAA_PP_REDUCE=1 and the
-    // ablation build keep the reduce launch)
-    const bool finish = pl.S > 1 && pl.S <= 4 && ctx.splitk_sync && !ctx.tune.pp_reduce_launch && ctx.tune.pp_dbg < 0 &&
-                        q.tiles <= SPLITK_SYNC_TILES && pp_lean_epilogue(p);
-    q.sync = finish ? ctx.splitk_sync : nullptr;
     q.dbg = ctx.tune.pp_dbg >= 0 ? ctx.tune.pp_dbg : 0;
     MAA_CHECK((q.nci + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
     MAA_CHECK(q.CAPl > 0, "igemm_pp: the A ring does not fit beside the weight ring");
-    const size_t lds = (size_t)q.CAPl * 128 + (size_t)NSB * BN * 128 + 128 + 1024 + 128;
+    const size_t lds = (size_t)q.CAPl * 128 + (size_t)NSB * BN * 128 + 128 + 1024;
     MAA_CHECK(lds <= 163840, "igemm_pp: LDS per workgroup");
     q.items = q.tiles * pl.S;
     const int cus = device_cu_count(ctx.device);
@@ -673,7 +504,7 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
         launch_npa<MI, NI, GWM, GWN, 1>(ctx, p, q, grid, lds);
     else
         launch_npa<MI, NI, GWM, GWN, 3>(ctx, p, q, grid, lds);
-    if (pl.S > 1 && !finish) launch_splitk_reduce(ctx, p, part, pl.S, q.tiles, ntiles, Nb, BM, BN, GWN, MI, NI, 512);
+    if (pl.S > 1) launch_splitk_reduce(ctx, p, part, pl.S, q.tiles, ntiles, Nb, BM, BN, GWN, MI, NI, 512);
 }
 
 

@@ -125,7 +125,6 @@ struct Tuning {
     bool no_halo = false;                   // MAA_NO_HALO: the narrow vocoder stages through the implicit GEMM (bit-identity test)
     bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
     bool gn_two_pass = false;               // MAA_GN_TWO_PASS=1: GroupNorm as the statistics + apply launches of rounds 1-4 everywhere (A/B, tests)
-    bool pp_reduce_launch = false;          // MAA_PP_REDUCE=1: igemm_pp's K slices finished by the separate reduce launch (rounds 3 / 4) instead of in the kernel
     bool cfg_split = true;                  // MAA_CFG_SPLIT=0: the two halves of a classifier-free-guidance step one after the other on one stream
     void load();
 };
@@ -148,10 +147,6 @@ struct Ctx {
     DevSlab sampler_scratch;  // DDIM loop state (tables, step slots, UNet input, eps): reused by every sample() call
     Profiler* prof = nullptr;
     float* zeros = nullptr;   // 256 B zero page (device), source of masked tile loads
-    // Arrival words of the in-kernel split-K finish (igemm_pp.hip): [SPLITK_SYNC_TILES][2] ints, zero between launches -- every
-    // tile's last-arriving K slice sets its pair back to zero.  One buffer per context (its launches are stream-ordered); the
-    // second CFG lane has its own.  Owned by the context (ctx_device_buffers / ~Ctx).
-    int* splitk_sync = nullptr;
     int device = 0;
     hipStream_t stream = nullptr;
     mutable Arena ws;    // (mutable: a launch may borrow scratch, e.g. split-K slabs, and give it back before it returns)
@@ -159,8 +154,6 @@ struct Ctx {
 };
 
 Ctx& side_lane(Ctx& ctx);      // the context's second lane (created on first use: stream, events)
-constexpr int SPLITK_SYNC_TILES = 8192;
-void ctx_device_buffers(Ctx& ctx);      // the context's small zero-initialised device buffers (split-K arrival words)
 
 // ------------------------------------------------------------------------------------------ igemm
 // Out[m, n] = epilogue( alpha * sum_k A[m, k] * B[k, n] ),  m = (b, oy, ox) output position,

@@ -296,20 +296,23 @@ struct GnFusedPlan {
 GnFusedPlan gn_fused_plan(int C, int C1, int HW, int groups) {
     GnFusedPlan pl;
     const int cpg = C / groups;
-    for (int gpb : {4, 2, 8, 1, 16}) {
-        if (groups % gpb) continue;
-        const int CB = gpb * cpg;
-        if (CB % 4 || CB > 512) continue;
-        const int Q = CB / 4, RL = 1024 / Q;
-        if (RL < 1) continue;
-        const int need = (HW + RL - 1) / RL;
-        if (need > 16) continue;
-        pl.gpb = gpb;
-        pl.nr = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : 16;
-        pl.threads = RL * Q;
-        pl.lds = ((size_t)RL * Q * 8 + 2 * CB + 2 * gpb) * sizeof(float);
-        return pl;
-    }
+    // at most eight float4 rows per thread where some block width allows it (no register pressure at 1024 threads), else
+    // twelve, else sixteen (which spills a little); wider blocks (longer contiguous runs per position) first
+    for (int cap : {8, 12, 16})
+        for (int gpb : {4, 2, 8, 1, 16}) {
+            if (groups % gpb) continue;
+            const int CB = gpb * cpg;
+            if (CB % 4 || CB > 512) continue;
+            const int Q = CB / 4, RL = 1024 / Q;
+            if (RL < 1) continue;
+            const int need = (HW + RL - 1) / RL;
+            if (need > cap) continue;
+            pl.gpb = gpb;
+            pl.nr = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : need <= 8 ? 8 : need <= 12 ? 12 : 16;
+            pl.threads = RL * Q;
+            pl.lds = ((size_t)RL * Q * 8 + 2 * CB + 2 * gpb) * sizeof(float);
+            return pl;
+        }
     return pl;
 }
 
@@ -483,6 +486,7 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
             case 2: go(gn_fused_kernel<2>); break;
             case 4: go(gn_fused_kernel<4>); break;
             case 8: go(gn_fused_kernel<8>); break;
+            case 12: go(gn_fused_kernel<12>); break;
             default: go(gn_fused_kernel<16>); break;
         }
         MAA_HIP(hipGetLastError());

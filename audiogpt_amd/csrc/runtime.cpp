@@ -174,7 +174,6 @@ void Tuning::load() {
     no_dma = !get_s("MAA_NO_DMA").empty();
     no_halo = !get_s("MAA_NO_HALO").empty();
     snake_untiled = !get_s("MAA_SNAKE_UNTILED").empty();
-    pp_reduce_launch = get_s("MAA_PP_REDUCE") == "1";
     gn_two_pass = get_s("MAA_GN_TWO_PASS") == "1";
     const std::string cs = get_s("MAA_CFG_SPLIT");
     cfg_split = cs.empty() || cs[0] != '0';
@@ -206,18 +205,10 @@ Ctx::~Ctx() {
         side->stream = nullptr;
         delete side->prof;
         side->prof = nullptr;
-        delete side;      // (~Ctx of the lane frees its own arrival words)
+        delete side;
     }
-    if (splitk_sync) (void)hipFree(splitk_sync);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
-}
-void ctx_device_buffers(Ctx& ctx) {
-    if (ctx.splitk_sync) return;
-    void* d = nullptr;
-    MAA_HIP(hipMalloc(&d, (size_t)SPLITK_SYNC_TILES * 2 * sizeof(int)));
-    ctx.splitk_sync = static_cast<int*>(d);
-    MAA_HIP(hipMemset(d, 0, (size_t)SPLITK_SYNC_TILES * 2 * sizeof(int)));
 }
 Ctx& side_lane(Ctx& ctx) {
     if (!ctx.side) {
@@ -228,7 +219,6 @@ Ctx& side_lane(Ctx& ctx) {
         sd->device = ctx.device;
         sd->zeros = ctx.zeros;
         ctx.side = sd;
-        ctx_device_buffers(*sd);
         MAA_HIP(hipEventCreateWithFlags(&ctx.ev_fork, hipEventDisableTiming));
         MAA_HIP(hipEventCreateWithFlags(&ctx.ev_join, hipEventDisableTiming));
     }

@@ -251,33 +251,3 @@ def test_cfg_halves_as_two_lanes_are_bit_identical_to_one_stream(golden, precisi
     finally:
         c.close()
 
-
-def test_unet_in_kernel_splitk_finish_equals_the_reduce_launch(golden):
-    """The whole T2A UNet (bias + time-embedding row add in conv1's epilogue, residual in conv2's) with the 3x3 convolutions'
-    K slices finished in the kernel (default) and by the reduce launch of rounds 3 / 4 (MAA_PP_REDUCE=1): bit-identical."""
-    import os
-    from audiogpt_amd.backend import Context, UNet, reload_tuning
-    g = golden("unet_t2a")
-    x, t, c = torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"])
-    x, t, c = torch.cat([x, x.flip(0), x]), torch.cat([t, t.flip(0), t]), torch.cat([c, c.flip(0), c])
-    ctx = Context("cuda:0", precision="bf16x3")
-    u = UNet(ctx, C.UNET_T2A, WT.make_unet_state_dict(C.UNET_T2A, seed=0))
-    out = {}
-    saved = os.environ.get("MAA_PP_REDUCE")
-    try:
-        for mode in ("1", "0"):
-            os.environ["MAA_PP_REDUCE"] = mode
-            reload_tuning()
-            ctx.prof_begin()
-            out[mode] = u(x, t, c).cpu()
-            rows = ctx.prof_end()
-            assert any(k.startswith("igemm_pp_bf16x3") and "splitK" in k for k in rows), rows.keys()
-    finally:
-        if saved is None:
-            os.environ.pop("MAA_PP_REDUCE", None)
-        else:
-            os.environ["MAA_PP_REDUCE"] = saved
-        reload_tuning()
-    assert torch.equal(out["0"], out["1"])
-    u.close()
-    ctx.close()

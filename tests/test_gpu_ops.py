@@ -170,3 +170,30 @@ def test_snake_antialiased_activation(ctx):
     filt = O.kaiser_sinc_filter1d(0.25, 0.3, 12)
     ref = O.downsample1d(O.snake(O.upsample1d(x, filt), al, be, True), filt)
     check("snake_aa", ctx.op_snake_aa(x, al, be, True), ref, 1e-5)
+
+
+@pytest.mark.parametrize("C,HW", [(320, 780), (640, 780), (960, 780), (640, 195), (1280, 195), (1920, 195), (256, 780), (512, 3120)])
+def test_groupnorm_one_pass_against_two_pass_and_batch_invariance(ctx, C, HW):
+    """Round 5: GroupNorm reads the tensor once (a workgroup keeps a sample's rows of a few groups in registers: norm.hip
+    gn_fused_kernel) where the registers hold them; MAA_GN_TWO_PASS=1 keeps the statistics + apply launches.  Both against torch,
+    the two against each other, and a sample alone against the same sample inside a batch (bit for bit: the layout is a function
+    of the layer, a workgroup sees one sample)."""
+    import os
+    from audiogpt_amd.backend import reload_tuning
+    x = torch.randn(5, C, HW, generator=g(128)) * 1.7 + 0.3
+    ga, be = torch.randn(C, generator=g(129)), torch.randn(C, generator=g(130))
+    ref = F.silu(F.group_norm(x, 32, ga, be, 1e-5))
+    y1 = ctx.op_groupnorm(x, ga, be, 1e-5, True).cpu()
+    y1b = ctx.op_groupnorm(x, ga, be, 1e-5, True).cpu()
+    one = ctx.op_groupnorm(x[3:4], ga, be, 1e-5, True).cpu()
+    os.environ["MAA_GN_TWO_PASS"] = "1"
+    try:
+        reload_tuning()
+        y2 = ctx.op_groupnorm(x, ga, be, 1e-5, True).cpu()
+    finally:
+        os.environ.pop("MAA_GN_TWO_PASS")
+        reload_tuning()
+    check(f"groupnorm_onepass_C{C}_HW{HW}", y1, ref, 2e-5)
+    check(f"groupnorm_twopass_C{C}_HW{HW}", y2, ref, 2e-5)
+    assert torch.equal(y1, y1b) and torch.equal(one, y1[3:4])
+    assert float((y1 - y2).abs().max()) <= 2e-5 * float(ref.abs().max())

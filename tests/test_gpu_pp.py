@@ -30,8 +30,8 @@ def ctx():
 class forced:
     """Environment for one call: the library parses the MAA_* knobs when a context is created: reload_tuning() re-reads them."""
 
-    def __init__(self, pp, presplit=True, pp1=None, dma2=None, reduce_launch=False):
-        self.env = {"MAA_PP": pp, "MAA_OP_PRESPLIT": "1" if presplit else "0", "MAA_PP_REDUCE": "1" if reduce_launch else "0"}
+    def __init__(self, pp, presplit=True, pp1=None, dma2=None):
+        self.env = {"MAA_PP": pp, "MAA_OP_PRESPLIT": "1" if presplit else "0"}
         if pp1 is not None:
             self.env["MAA_PP1"] = pp1
         if dma2 is not None:
@@ -75,25 +75,6 @@ def test_conv3x3(ctx, variant, B, Cin, Cout, H, W):
     with forced(variant):
         y = ctx.op_conv(x, w, b, pad=1)
     check(f"pp[{variant}]_conv3x3_{Cin}_{Cout}_{H}x{W}_b{B}", y, F.conv2d(x, w, b, padding=1), TOL)
-
-
-@pytest.mark.parametrize("variant", ["128,2", "128,3", "128,4", "160,2", "160,3", "160,4"])
-@pytest.mark.parametrize("B,Cin,Cout,H,W", CONVS[:3] + [(16, 320, 320, 10, 78)])
-def test_in_kernel_splitk_finish_equals_the_reduce_launch(ctx, variant, B, Cin, Cout, H, W):
-    """Round 5: the K slices of a tile are finished inside the kernel by whichever slice arrives last (ticket, slabs published
-    write-through, the sum taken in slice order, lean fused epilogue) instead of by a second launch over S slabs.  Same sums in
-    the same order: bit-identical to the reduce launch (MAA_PP_REDUCE=1), run after run -- the last arriver differs from run to
-    run and from tile to tile, the result must not."""
-    x = torch.randn(B, Cin, H, W, generator=g(41))
-    w = torch.randn(Cout, Cin, 3, 3, generator=g(42)) / math.sqrt(9 * Cin)
-    b = torch.randn(Cout, generator=g(43))
-    with forced(variant, reduce_launch=True):
-        ref = ctx.op_conv(x, w, b, pad=1).cpu()
-    with forced(variant):
-        for rep in range(4):
-            y = ctx.op_conv(x, w, b, pad=1).cpu()
-            assert torch.equal(y, ref), (variant, rep, float((y - ref).abs().max()))
-    check(f"pp_finish[{variant}]_conv3x3_{Cin}_{Cout}_{H}x{W}_b{B}", y, F.conv2d(x, w, b, padding=1), TOL)
 
 
 def test_position_and_channel_probe(ctx):
