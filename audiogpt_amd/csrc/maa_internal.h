@@ -125,6 +125,7 @@ struct Tuning {
     bool no_halo = false;                   // MAA_NO_HALO: the narrow vocoder stages through the implicit GEMM (bit-identity test)
     bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
     bool no_partials = false;               // MAA_NO_PARTIALS=1: the ResBlock's first convolution reduces its K slices itself (reduce launch) instead of handing them to GroupNorm
+    int gn_gpb = 0, gn_threads = 1024;      // MAA_GN_GPB / MAA_GN_THREADS: layout sweep of the one-pass GroupNorm (groups per workgroup, threads per workgroup)
     bool gn_two_pass = false;               // MAA_GN_TWO_PASS=1: GroupNorm as the statistics + apply launches of rounds 1-4 everywhere (A/B, tests)
     bool cfg_split = true;                  // MAA_CFG_SPLIT=0: the two halves of a classifier-free-guidance step one after the other on one stream
     void load();

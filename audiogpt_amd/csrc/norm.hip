@@ -362,7 +362,7 @@ struct GnFusedPlan {
     int gpb = 0, nr = 0, threads = 0;
     size_t lds = 0;
 };
-GnFusedPlan gn_fused_plan(int C, int C1, int HW, int groups) {
+GnFusedPlan gn_fused_plan(int C, int C1, int HW, int groups, int force_gpb = 0, int max_threads = 1024) {
     GnFusedPlan pl;
     const int cpg = C / groups;
     // at most eight float4 rows per thread where some block width allows it (no register pressure at 1024 threads), else
@@ -370,9 +370,10 @@ GnFusedPlan gn_fused_plan(int C, int C1, int HW, int groups) {
     for (int cap : {8, 12, 16})
         for (int gpb : {4, 2, 8, 1, 16}) {
             if (groups % gpb) continue;
+            if (force_gpb && gpb != force_gpb) continue;
             const int CB = gpb * cpg;
             if (CB % 4 || CB > 512) continue;
-            const int Q = CB / 4, RL = 1024 / Q;
+            const int Q = CB / 4, RL = max_threads / Q;
             if (RL < 1) continue;
             const int need = (HW + RL - 1) / RL;
             if (need > cap) continue;
@@ -382,6 +383,7 @@ GnFusedPlan gn_fused_plan(int C, int C1, int HW, int groups) {
             pl.lds = ((size_t)RL * Q * 8 + 2 * CB + 2 * gpb) * sizeof(float);
             return pl;
         }
+    if (force_gpb) return gn_fused_plan(C, C1, HW, groups, 0, max_threads);      // (the forced width does not divide this shape)
     return pl;
 }
 
@@ -566,7 +568,7 @@ void launch_gn_fused(const Ctx& ctx, const GnFusedPlan& fp, const float* x1, int
 // per thread (two slices' loads in flight: 2 x 8 float4)
 bool groupnorm_takes_partials(const Ctx& ctx, int C, int HW, int groups) {
     if (ctx.tune.gn_two_pass || ctx.tune.no_partials || C % groups || C % 4) return false;
-    const GnFusedPlan fp = gn_fused_plan(C, C, HW, groups);
+    const GnFusedPlan fp = gn_fused_plan(C, C, HW, groups, ctx.tune.gn_gpb, ctx.tune.gn_threads);
     return fp.gpb != 0 && fp.nr <= 8;
 }
 
@@ -575,7 +577,7 @@ void launch_groupnorm_partials(Ctx& ctx, const float* parts, int S, long long ps
                                const float* beta, float eps, int silu, float* out, int out_split) {
     if (ctx.ws.dry) return;
     MAA_CHECK(S >= 2 && S <= PARTIALS_MAX_S && groupnorm_takes_partials(ctx, C, HW, groups), "groupnorm over partials: shape / slices");
-    const GnFusedPlan fp = gn_fused_plan(C, C, HW, groups);
+    const GnFusedPlan fp = gn_fused_plan(C, C, HW, groups, ctx.tune.gn_gpb, ctx.tune.gn_threads);
     ProfScope prof(ctx, "groupnorm", 0.0, 4.0 * B * (double)HW * C * (S + 1));
     GnParts gp;
     gp.S = S;
@@ -596,7 +598,7 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
     MAA_CHECK(C % groups == 0 && C / groups <= 256 && C % 4 == 0 && C1 % 4 == 0 && ld1 % 4 == 0 && (C2 == 0 || ld2 % 4 == 0),
               "groupnorm channels");
     ProfScope prof(ctx, "groupnorm", 0.0, 8.0 * B * (double)HW * C);
-    const GnFusedPlan fp = ctx.tune.gn_two_pass ? GnFusedPlan() : gn_fused_plan(C, C1, HW, groups);
+    const GnFusedPlan fp = ctx.tune.gn_two_pass ? GnFusedPlan() : gn_fused_plan(C, C1, HW, groups, ctx.tune.gn_gpb, ctx.tune.gn_threads);
     if (fp.gpb) {
         launch_gn_fused<false>(ctx, fp, x1, ld1, C1, x2, ld2, C2, B, HW, groups, gamma, beta, eps, silu, out, out_split, raw_split, GnParts());
         return;
