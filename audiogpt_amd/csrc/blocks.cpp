@@ -55,9 +55,6 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
     p.c2 = o.c2;
     p.ldc2 = out.C;
     p.c2_slope = o.c2_slope;
-    p.partials = o.partials;
-    p.partials_S = o.partials_S;
-    if (p.partials_S) *p.partials_S = 0;
     launch_igemm(ctx, p);
 }
 

@@ -41,8 +41,6 @@ struct ConvOpt {
     int c_split = 0;              // write the output as split32 lines
     float* c2 = nullptr;          // second output: leaky-relu(c2_slope) of the result as split32 lines (output's shape)
     float c2_slope = 1.f;
-    float* partials = nullptr;    // IGemm::partials / partials_S: K-slice partial sums handed to the consumer
-    int* partials_S = nullptr;
 };
 
 // out = conv(x1 ++ x2) with packed weight `w`; output spatial size given by (Ho, Wo)

@@ -414,7 +414,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         const size_t mk = ctx.ws.mark();
         const size_t nf = igemm_pp_workspace_floats(p, planp);
         float* part = nf ? ctx.ws.alloc_f(nf) : nullptr;
-        {      // (also in the workspace dry run: whether the K slices are handed to the consumer is decided in there)
+        if (!ctx.ws.dry) {
             char shapep[64];
             const char* namep = igemm_pp_name(planp);
             if (ctx.prof && ctx.prof->detail) {
@@ -423,7 +423,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
             }
             ProfScope profp(ctx, namep, 2.0 * p.M * (double)ncols * p.K, 4.0 * ((double)p.K * ncols + (double)p.M * p.N));
             launch_igemm_pp(ctx, p, Nb, planp, part);
-            if (!ctx.ws.dry) MAA_HIP(hipGetLastError());
+            MAA_HIP(hipGetLastError());
         }
         ctx.ws.release(mk);
         return true;

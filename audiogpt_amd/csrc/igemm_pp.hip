@@ -75,8 +75,7 @@ struct PPArgs {
     int items;           // tiles x K slices
     int nci, cps;        // channel chunks in all, per K slice
     int Nb;              // rows of the packed weight that exist
-    float* part;         // split-K slabs or null (rowmajor: the K slices' row-major partial tensors, IGemm::partials)
-    int rowmajor;
+    float* part;         // split-K slabs or null
     int dbg;             // TUNE instantiation only (MAA_PP_DBG): 1 no MFMAs, 2 no copies after the prologue, 4 no fragment reads, 8 no vmcnt wait
 };
 
@@ -86,9 +85,8 @@ struct PPArgs {
 // PERSIST = false: a launch whose grid covers every item (the UNet's: 196-208 items on 256 CUs) -- the epilogue does not carry
 // the next item's staging state, which is what made the 256 x 160 instantiation spill 81 VGPRs
 // OUT: 0 = the result leaves through the fused epilogue or as a split-K slab (run-time choice; the TUNE build), 1 = epilogue
-// only, 2 = slab only -- the UNet's second ResBlock convolutions, and an instantiation without the epilogue's registers
-// has no scratch at all --, 3 = K-slice partials as row-major fp32 tensors for a consumer that sums them itself (round 5: the
-// ResBlock's first convolution -> the one-pass GroupNorm; no reduce launch, IGemm::partials)
+// only, 2 = slab only -- the UNet's launches are all of the last kind, and an instantiation without the epilogue's registers
+// has no scratch at all
 template <int MI, int NI, int GWM, int GWN, int NPA, bool TUNE, bool PERSIST, int OUT>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPArgs q) {
     constexpr int BN = GWN * NI * 32;
@@ -128,7 +126,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     const int TAPS = q.T;
     const int W = q.W, H = q.H;
     const long long Mtot = p.M;
-    int item = 0, m0 = 0, n0 = 0, c_begin = 0, c_end = 0, NQ = 0, cur_slice = 0;
+    int item = 0, m0 = 0, n0 = 0, c_begin = 0, c_end = 0, NQ = 0;
 
     // zero line (read by lanes whose tap is outside the image)
     if (tid < 8) *reinterpret_cast<f32x4*>(sZ + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -170,7 +168,6 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         // (the quotients are wave-uniform but come out of the VALU's division sequence: back into SGPRs)
         const int slice = __builtin_amdgcn_readfirstlane(item / q.tiles), tile = item - slice * q.tiles;
         const int mt = __builtin_amdgcn_readfirstlane(tile / q.ntiles), nt = tile - mt * q.ntiles;
-        cur_slice = slice;
         m0 = mt * BM;
         n0 = nt * BN;
         c_begin = slice * q.cps;
@@ -377,7 +374,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         }
         // Every fragment read of this item is done (a wave gets here through the barrier that follows group 1's last memory
         // phase): the next item's first copies may overwrite the rings while this item's results are stored.
-        const int e_item = item, e_m0 = m0, e_n0 = n0, e_slice = cur_slice;
+        const int e_item = item, e_m0 = m0, e_n0 = n0;
         const int w_next = w_cur + w_step;
         bool more = false;
         if constexpr (PERSIST) {
@@ -393,31 +390,6 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         const int row_base = e_m0 + grp * 128 + wm * (32 * MI), col_base = e_n0 + wn * (32 * NI);
         if (OUT == 1 || (OUT == 0 && q.part == nullptr)) {
             igemm_epilogue<MI, NI>(p, acc, row_base, col_base, lrow, lk, 0, q.Nb, rpb);
-        } else if constexpr (OUT == 3) {
-            // raw sums of this K slice, row-major [M][N] (N even: fp32 column pairs as 8-byte stores, igemm_epilogue.h PAIR)
-            float* const pp = q.part + (long long)e_slice * ((long long)p.M * p.N);
-            const bool even = (lrow & 1) == 0;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int jn = 0; jn < NI; ++jn) {
-                    const int n = col_base + jn * 32 + lrow;
-                    if (n < p.N) {
-#pragma unroll
-                        for (int rp = 0; rp < 8; ++rp) {
-                            const float keep = even ? acc[i][jn][2 * rp] : acc[i][jn][2 * rp + 1];
-                            const float give = even ? acc[i][jn][2 * rp + 1] : acc[i][jn][2 * rp];
-                            const float got = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, false));
-                            const int r = 2 * rp + (even ? 0 : 1);
-                            const int m = row_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                            if (m < p.M) {
-                                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                                const f32x2 v2 = even ? f32x2{keep, got} : f32x2{got, keep};
-                                *reinterpret_cast<f32x2*>(pp + (long long)m * p.N + (n & ~1)) = v2;
-                            }
-                        }
-                    }
-                }
         } else {
             // slab of this (slice, tile): [MI NI blocks][4 register quads][512 threads][4 floats]
             float* pp = q.part + ((long long)e_item * (MI * NI * 4) * 512 + tid) * 4;
@@ -488,10 +460,6 @@ void launch_npa(const Ctx& ctx, const IGemm& p, const PPArgs& q, int items, size
         hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
     };
     const bool persist = q.items > items, slab = q.part != nullptr;      // (more items than workgroups: persistent)
-    if (q.rowmajor) {      // (launch_one hands partials over only for launches of one item per workgroup and 3x3 geometry)
-        if constexpr (NPA == 1) go(igemm_pp_kernel<MI, NI, GWM, GWN, 1, false, false, 3>);
-        return;
-    }
     if (persist && slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 2>);
     else if (persist) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 1>);
     else if (slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, false, 2>);
@@ -524,7 +492,6 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     q.cps = (q.nci + pl.S - 1) / pl.S;
     q.Nb = Nb;
     q.part = pl.S > 1 ? part : nullptr;
-    q.rowmajor = 0;
     q.dbg = ctx.tune.pp_dbg >= 0 ? ctx.tune.pp_dbg : 0;
     MAA_CHECK((q.nci + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
     MAA_CHECK(q.CAPl > 0, "igemm_pp: the A ring does not fit beside the weight ring");
@@ -533,17 +500,6 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     q.items = q.tiles * pl.S;
     const int cus = device_cu_count(ctx.device);
     const int grid = q.items < cus ? q.items : cus;          // persistent: one workgroup per CU holds the LDS
-    // the K slices' sums handed to the consumer (IGemm::partials): no slab, no reduce launch
-    const bool hand_over = p.partials && p.partials_S && pl.S > 1 && pl.S <= PARTIALS_MAX_S && g.npa == 1 && q.items <= cus &&
-                           ctx.tune.pp_dbg < 0 && (p.N & 1) == 0 && (reinterpret_cast<uintptr_t>(p.partials) & 7) == 0 && p.Z == 1 && !p.geglu;
-    if (hand_over) {
-        q.part = p.partials;
-        q.rowmajor = 1;
-        *p.partials_S = pl.S;
-        if (!ctx.ws.dry) launch_npa<MI, NI, GWM, GWN, 1>(ctx, p, q, grid, lds);
-        return;
-    }
-    if (ctx.ws.dry) return;
     if (g.npa == 1)
         launch_npa<MI, NI, GWM, GWN, 1>(ctx, p, q, grid, lds);
     else

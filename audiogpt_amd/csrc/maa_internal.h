@@ -124,8 +124,6 @@ struct Tuning {
     bool no_dma = false;                    // MAA_NO_DMA: every bf16 contraction on the register-staged engine (bit-identity tests)
     bool no_halo = false;                   // MAA_NO_HALO: the narrow vocoder stages through the implicit GEMM (bit-identity test)
     bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
-    bool no_partials = false;               // MAA_NO_PARTIALS=1: the ResBlock's first convolution reduces its K slices itself (reduce launch) instead of handing them to GroupNorm
-    int gn_gpb = 0, gn_threads = 1024;      // MAA_GN_GPB / MAA_GN_THREADS: layout sweep of the one-pass GroupNorm (groups per workgroup, threads per workgroup)
     bool gn_two_pass = false;               // MAA_GN_TWO_PASS=1: GroupNorm as the statistics + apply launches of rounds 1-4 everywhere (A/B, tests)
     bool cfg_split = true;                  // MAA_CFG_SPLIT=0: the two halves of a classifier-free-guidance step one after the other on one stream
     void load();
@@ -202,19 +200,11 @@ struct IGemm {
     float* c2 = nullptr;
     int ldc2 = 0;
     float c2_slope = 1.f;
-    // K-slice partial sums handed to the consumer instead of being reduced (the ResBlock's first convolution -> the one-pass
-    // GroupNorm that is its only reader, norm.hip): when `partials` is set and the engine that takes the problem runs it in S > 1
-    // K slices, slice s writes its raw sums (no alpha / bias / row add / residual) as a row-major fp32 tensor at
-    // partials + s * M * N (row pitch N), no reduce launch follows, nothing is written to `c`, and *partials_S = S (host word);
-    // otherwise the problem runs as usual and *partials_S = 0.  The caller provides room for PARTIALS_MAX_S slices.
-    float* partials = nullptr;
-    int* partials_S = nullptr;
     int no_pair = 0;                 // (A/B, retired) plain 4-byte fp32 stores in the epilogue
     const float* zeros = nullptr;    // >= 16 B of zeros in device memory (filled in by launch_igemm)
     int m_fastest = 0;               // tile order inside an XCD's range: 1 = M-tiles fastest (MAA_TILE_ORDER=1: weights are
                                      // then fetched once chip-wide, but the conv's A re-reads lose their L2: +4 % step time)
 };
-constexpr int PARTIALS_MAX_S = 4;
 void launch_igemm(const Ctx& ctx, const IGemm& p);
 // Tile choice shared by the fp32 and bf16 engines: 0 = 128x128, 1 = 128x64, 2 = 64x64 (3 = 256x32 is chosen by
 // the callers for N <= 32).  Cost = CU-rounds x tile area / (tile efficiency x latency hiding at that many
@@ -263,14 +253,6 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
                       int groups, const float* gamma, const float* beta, float eps, int silu, float* out,
                       int out_split = 0, float* raw_split = nullptr);
 // raw_split: optional second output [B, HW, C1+C2] -- the UN-normalised (x1 | x2) rows as split32 lines (C % 32 == 0)
-// The same over x = ((p_0 + p_1) + ...) * alpha + bias [+ rowadd[sample]] formed on the fly from S K-slice partial tensors
-// (IGemm::partials; slice pitch `pstride` floats, row pitch C): what the reduce launch + epilogue would have written, never
-// materialised.  false: the shape does not fit the one-pass kernel (the caller must not have deferred the reduction:
-// groupnorm_takes_partials says beforehand).
-bool groupnorm_takes_partials(const Ctx& ctx, int C, int HW, int groups);
-void launch_groupnorm_partials(Ctx& ctx, const float* parts, int S, long long pstride, float alpha, const float* bias,
-                               const float* rowadd, int ld_rowadd, int C, int B, int HW, int groups, const float* gamma,
-                               const float* beta, float eps, int silu, float* out, int out_split);
 void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, const float* gamma, const float* beta,
                       float eps, float* out, int out_split = 0);
 // fp32 [rows, C] -> split32 rows of the same pitch (C % 32 == 0): tests and micro-benchmarks of the engines that take

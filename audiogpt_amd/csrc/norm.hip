@@ -169,23 +169,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 // sums of d = x - pivot and d^2 with the group's first element as pivot, scale = gamma rstd, shift = beta - mean scale,
 // y = x scale + shift.  The layout (GPB, RL, NR) is a function of (C, HW) only and a workgroup sees one sample: a sample's result
 // does not depend on its batch.
-// PARTS: x is not in memory -- x1 holds S K-slice partial tensors of the convolution that produces it (slice pitch `pstride`
-// floats, row pitch C) and x = ((p_0 + p_1) + ...) alpha + bias [+ rowadd[sample]] is formed while loading, in the order the
-// reduce launch + igemm epilogue use (bit-identical to what they would have written).
-struct GnParts {
-    int S = 0;
-    long long pstride = 0;
-    float alpha = 1.f;
-    const float* bias = nullptr;
-    const float* rowadd = nullptr;
-    int ld_rowadd = 0;
-};
-template <int NR, bool PARTS>
+template <int NR>
 __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict__ x1, int ld1, int C1,
                                                         const float* __restrict__ x2, int ld2, int C2, int HW, int groups,
                                                         int GPB, float eps, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int silu, float* __restrict__ out,
-                                                        int split, float* __restrict__ raw_split, const GnParts gp) {
+                                                        int split, float* __restrict__ raw_split) {
     extern __shared__ float gsm[];      // red[RL Q 8] | colsum[2 CB] | gstat[2 GPB]
     const int C = C1 + C2, cpg = C / groups, CB = GPB * cpg, Q = CB >> 2;
     const int RL = (int)blockDim.x / Q;                      // (blockDim.x == RL Q)
@@ -204,79 +193,20 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
         src = x2 + (long long)b * HW * ld2 + (c - C1);
         ld = ld2;
     }
-    // element (row 0, channel cc) of this sample: the pivots
-    auto first_of = [&](int cc) -> float {
-        if constexpr (PARTS) {
-            const float* p0 = x1 + (long long)b * HW * C + cc;
-            float sacc = p0[0];
-            for (int sl = 1; sl < gp.S; ++sl) sacc += p0[(long long)sl * gp.pstride];
-            float val = sacc * gp.alpha + (gp.bias ? gp.bias[cc] : 0.f);
-            if (gp.rowadd) val += gp.rowadd[(long long)b * gp.ld_rowadd + cc];
-            return val;
-        } else {
-            return cc < C1 ? x1[(long long)b * HW * ld1 + cc] : x2[(long long)b * HW * ld2 + (cc - C1)];
-        }
-    };
     // pivot of each of the float4's four channels = first element of that channel's group
     int gl[4];
     float piv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         gl[j] = (4 * tx + j) / cpg;
-        piv[j] = first_of(c_lo + gl[j] * cpg);
+        const int c0 = c_lo + gl[j] * cpg;
+        piv[j] = c0 < C1 ? x1[(long long)b * HW * ld1 + c0] : x2[(long long)b * HW * ld2 + (c0 - C1)];
     }
     float4 v[NR];
-    if constexpr (PARTS) {
-        // two slices' loads in flight at a time; sums in slice order ((p0 + p1) + p2) + p3
-        const float* pbase = x1 + (long long)b * HW * C + c;
-        float4 t0[NR], t1[NR];
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int r = ty + RL * k;
-            const long long o = (long long)(r < HW ? r : 0) * C;
-            t0[k] = *reinterpret_cast<const float4*>(pbase + o);
-            t1[k] = *reinterpret_cast<const float4*>(pbase + gp.pstride + o);
-        }
-#pragma unroll
-        for (int k = 0; k < NR; ++k) v[k] = make_float4(t0[k].x + t1[k].x, t0[k].y + t1[k].y, t0[k].z + t1[k].z, t0[k].w + t1[k].w);
-        if (gp.S > 2) {
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                const int r = ty + RL * k;
-                const long long o = (long long)(r < HW ? r : 0) * C;
-                t0[k] = *reinterpret_cast<const float4*>(pbase + 2 * gp.pstride + o);
-                if (gp.S > 3) t1[k] = *reinterpret_cast<const float4*>(pbase + 3 * gp.pstride + o);
-            }
-#pragma unroll
-            for (int k = 0; k < NR; ++k) {
-                v[k] = make_float4(v[k].x + t0[k].x, v[k].y + t0[k].y, v[k].z + t0[k].z, v[k].w + t0[k].w);
-                if (gp.S > 3) v[k] = make_float4(v[k].x + t1[k].x, v[k].y + t1[k].y, v[k].z + t1[k].z, v[k].w + t1[k].w);
-            }
-        }
-        const float4 bi = gp.bias ? *reinterpret_cast<const float4*>(gp.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 ra = gp.rowadd ? *reinterpret_cast<const float4*>(gp.rowadd + (long long)b * gp.ld_rowadd + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int r = ty + RL * k;
-            float4 e;
-            e.x = v[k].x * gp.alpha + bi.x;
-            e.y = v[k].y * gp.alpha + bi.y;
-            e.z = v[k].z * gp.alpha + bi.z;
-            e.w = v[k].w * gp.alpha + bi.w;
-            if (gp.rowadd) {
-                e.x += ra.x;
-                e.y += ra.y;
-                e.z += ra.z;
-                e.w += ra.w;
-            }
-            v[k] = r < HW ? e : make_float4(piv[0], piv[1], piv[2], piv[3]);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int r = ty + RL * k;
-            v[k] = r < HW ? *reinterpret_cast<const float4*>(src + (long long)r * ld) : make_float4(piv[0], piv[1], piv[2], piv[3]);
-        }
+    for (int k = 0; k < NR; ++k) {
+        const int r = ty + RL * k;
+        v[k] = r < HW ? *reinterpret_cast<const float4*>(src + (long long)r * ld) : make_float4(piv[0], piv[1], piv[2], piv[3]);
     }
     float sd[4] = {0.f, 0.f, 0.f, 0.f}, qd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -319,7 +249,8 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
             s += colsum[t * cpg + i];
             q += colsum[CB + t * cpg + i];
         }
-        const float pv = first_of(c_lo + t * cpg);
+        const int c0 = c_lo + t * cpg;
+        const float pv = c0 < C1 ? x1[(long long)b * HW * ld1 + c0] : x2[(long long)b * HW * ld2 + (c0 - C1)];
         const float n = (float)HW * (float)cpg;
         const float sm = s / n, qm = q / n;
         const float var = fmaxf(qm - sm * sm, 0.f);
@@ -362,7 +293,7 @@ struct GnFusedPlan {
     int gpb = 0, nr = 0, threads = 0;
     size_t lds = 0;
 };
-GnFusedPlan gn_fused_plan(int C, int C1, int HW, int groups, int force_gpb = 0, int max_threads = 1024) {
+GnFusedPlan gn_fused_plan(int C, int C1, int HW, int groups) {
     GnFusedPlan pl;
     const int cpg = C / groups;
     // at most eight float4 rows per thread where some block width allows it (no register pressure at 1024 threads), else
@@ -370,10 +301,9 @@ GnFusedPlan gn_fused_plan(int C, int C1, int HW, int groups, int force_gpb = 0, 
     for (int cap : {8, 12, 16})
         for (int gpb : {4, 2, 8, 1, 16}) {
             if (groups % gpb) continue;
-            if (force_gpb && gpb != force_gpb) continue;
             const int CB = gpb * cpg;
             if (CB % 4 || CB > 512) continue;
-            const int Q = CB / 4, RL = max_threads / Q;
+            const int Q = CB / 4, RL = 1024 / Q;
             if (RL < 1) continue;
             const int need = (HW + RL - 1) / RL;
             if (need > cap) continue;
@@ -383,7 +313,6 @@ GnFusedPlan gn_fused_plan(int C, int C1, int HW, int groups, int force_gpb = 0, 
             pl.lds = ((size_t)RL * Q * 8 + 2 * CB + 2 * gpb) * sizeof(float);
             return pl;
         }
-    if (force_gpb) return gn_fused_plan(C, C1, HW, groups, 0, max_threads);      // (the forced width does not divide this shape)
     return pl;
 }
 
@@ -536,59 +465,6 @@ void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, 
     MAA_HIP(hipGetLastError());
 }
 
-namespace {
-template <bool PARTS>
-void launch_gn_fused(const Ctx& ctx, const GnFusedPlan& fp, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int B,
-                     int HW, int groups, const float* gamma, const float* beta, float eps, int silu, float* out, int out_split,
-                     float* raw_split, const GnParts& gp) {
-    dim3 grid((unsigned)(groups / fp.gpb), (unsigned)B);
-    auto go = [&](auto kern) {
-        hipLaunchKernelGGL(kern, grid, dim3((unsigned)fp.threads), fp.lds, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW, groups, fp.gpb, eps,
-                           gamma, beta, silu, out, out_split, raw_split, gp);
-    };
-    switch (fp.nr) {
-        case 1: go(gn_fused_kernel<1, PARTS>); break;
-        case 2: go(gn_fused_kernel<2, PARTS>); break;
-        case 4: go(gn_fused_kernel<4, PARTS>); break;
-        case 8: go(gn_fused_kernel<8, PARTS>); break;
-        default:
-            if constexpr (!PARTS) {      // (partials are only handed over where eight rows per thread suffice)
-                if (fp.nr == 12)
-                    go(gn_fused_kernel<12, false>);
-                else
-                    go(gn_fused_kernel<16, false>);
-            }
-            break;
-    }
-    MAA_HIP(hipGetLastError());
-}
-}  // namespace
-
-// The one-pass kernel can form its input from K-slice partial sums when it takes the shape at all and keeps at most eight rows
-// per thread (two slices' loads in flight: 2 x 8 float4)
-bool groupnorm_takes_partials(const Ctx& ctx, int C, int HW, int groups) {
-    if (ctx.tune.gn_two_pass || ctx.tune.no_partials || C % groups || C % 4) return false;
-    const GnFusedPlan fp = gn_fused_plan(C, C, HW, groups, ctx.tune.gn_gpb, ctx.tune.gn_threads);
-    return fp.gpb != 0 && fp.nr <= 8;
-}
-
-void launch_groupnorm_partials(Ctx& ctx, const float* parts, int S, long long pstride, float alpha, const float* bias,
-                               const float* rowadd, int ld_rowadd, int C, int B, int HW, int groups, const float* gamma,
-                               const float* beta, float eps, int silu, float* out, int out_split) {
-    if (ctx.ws.dry) return;
-    MAA_CHECK(S >= 2 && S <= PARTIALS_MAX_S && groupnorm_takes_partials(ctx, C, HW, groups), "groupnorm over partials: shape / slices");
-    const GnFusedPlan fp = gn_fused_plan(C, C, HW, groups, ctx.tune.gn_gpb, ctx.tune.gn_threads);
-    ProfScope prof(ctx, "groupnorm", 0.0, 4.0 * B * (double)HW * C * (S + 1));
-    GnParts gp;
-    gp.S = S;
-    gp.pstride = pstride;
-    gp.alpha = alpha;
-    gp.bias = bias;
-    gp.rowadd = rowadd;
-    gp.ld_rowadd = ld_rowadd;
-    launch_gn_fused<true>(ctx, fp, parts, C, C, nullptr, 0, 0, B, HW, groups, gamma, beta, eps, silu, out, out_split, nullptr, gp);
-}
-
 void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x2, int ld2, int C2, int B, int HW,
                       int groups, const float* gamma, const float* beta, float eps, int silu, float* out,
                       int out_split, float* raw_split) {
@@ -598,9 +474,22 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
     MAA_CHECK(C % groups == 0 && C / groups <= 256 && C % 4 == 0 && C1 % 4 == 0 && ld1 % 4 == 0 && (C2 == 0 || ld2 % 4 == 0),
               "groupnorm channels");
     ProfScope prof(ctx, "groupnorm", 0.0, 8.0 * B * (double)HW * C);
-    const GnFusedPlan fp = ctx.tune.gn_two_pass ? GnFusedPlan() : gn_fused_plan(C, C1, HW, groups, ctx.tune.gn_gpb, ctx.tune.gn_threads);
+    const GnFusedPlan fp = ctx.tune.gn_two_pass ? GnFusedPlan() : gn_fused_plan(C, C1, HW, groups);
     if (fp.gpb) {
-        launch_gn_fused<false>(ctx, fp, x1, ld1, C1, x2, ld2, C2, B, HW, groups, gamma, beta, eps, silu, out, out_split, raw_split, GnParts());
+        dim3 grid((unsigned)(groups / fp.gpb), (unsigned)B);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, grid, dim3((unsigned)fp.threads), fp.lds, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW, groups, fp.gpb, eps,
+                               gamma, beta, silu, out, out_split, raw_split);
+        };
+        switch (fp.nr) {
+            case 1: go(gn_fused_kernel<1>); break;
+            case 2: go(gn_fused_kernel<2>); break;
+            case 4: go(gn_fused_kernel<4>); break;
+            case 8: go(gn_fused_kernel<8>); break;
+            case 12: go(gn_fused_kernel<12>); break;
+            default: go(gn_fused_kernel<16>); break;
+        }
+        MAA_HIP(hipGetLastError());
         return;
     }
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * groups), dim3(256), 0, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW, groups,

@@ -175,10 +175,6 @@ void Tuning::load() {
     no_halo = !get_s("MAA_NO_HALO").empty();
     snake_untiled = !get_s("MAA_SNAKE_UNTILED").empty();
     gn_two_pass = get_s("MAA_GN_TWO_PASS") == "1";
-    gn_gpb = std::atoi(get_s("MAA_GN_GPB").c_str());
-    gn_threads = get_s("MAA_GN_THREADS").empty() ? 1024 : std::atoi(get_s("MAA_GN_THREADS").c_str());
-    if (gn_threads < 64 || gn_threads > 1024) gn_threads = 1024;
-    no_partials = get_s("MAA_NO_PARTIALS") == "1";
     const std::string cs = get_s("MAA_CFG_SPLIT");
     cfg_split = cs.empty() || cs[0] != '0';
     // a stale override in an older round's format ("2,2,0,1": tile, stages ...) is refused here, when the context is created

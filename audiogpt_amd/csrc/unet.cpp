@@ -275,7 +275,6 @@ struct UNet::Impl {
         o1.rowadd = emb_out + r.emb_off;
         o1.ld_rowadd = emb_ld;
         const float* resid = nullptr;
-        int partials_S = 0;
         if (r.updown == 1) {          // openaimodel.py:212-214,256-261: avg-pool both h and x, then conv
             MAA_CHECK(!x2, "down ResBlock takes one source");
             T4 tp = alloc_t(ctx, B, Ho, Wo, r.cin), xp = alloc_t(ctx, B, Ho, Wo, r.cin);
@@ -291,23 +290,12 @@ struct UNet::Impl {
             conv_into(ctx, t1, nullptr, r.conv1, o1, h1);
             resid = xu.p;
         } else {
-            // h = conv1(...) + emb has ONE reader, GroupNorm (openaimodel.py:262-270): where the convolution runs in K slices and the
-            // one-pass GroupNorm takes the shape, the slices' partial sums go straight to it -- bias and the time-embedding row are
-            // added while it loads -- and neither the reduce launch nor h itself exist
-            if (groupnorm_takes_partials(ctx, r.cout, Ho * Wo, 32)) {
-                o1.partials = ctx.ws.alloc_f((size_t)PARTIALS_MAX_S * B * Ho * Wo * r.cout);
-                o1.partials_S = &partials_S;
-            }
             conv_into(ctx, t1, nullptr, r.conv1, o1, h1);
             resid = x1.p;
         }
         T4 t2 = alloc_t(ctx, B, Ho, Wo, r.cout);
         t2.split = split_for_gemm(ctx, r.cout);
-        if (partials_S > 0)
-            launch_groupnorm_partials(ctx, o1.partials, partials_S, (long long)B * Ho * Wo * r.cout, 1.f, r.conv1.bias, o1.rowadd,
-                                      o1.ld_rowadd, r.cout, B, Ho * Wo, 32, r.g2, r.b2, 1e-5f, 1, t2.p, t2.split);
-        else
-            launch_groupnorm(ctx, h1.p, r.cout, r.cout, nullptr, 0, 0, B, Ho * Wo, 32, r.g2, r.b2, 1e-5f, 1, t2.p, t2.split);
+        launch_groupnorm(ctx, h1.p, r.cout, r.cout, nullptr, 0, 0, B, Ho * Wo, 32, r.g2, r.b2, 1e-5f, 1, t2.p, t2.split);
         if (r.has_skip) {
             MAA_CHECK(r.updown == 0, "skip conv with up/down");
             T4 sk = alloc_t(ctx, B, H, W, r.cout);

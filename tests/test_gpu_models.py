@@ -252,33 +252,3 @@ def test_cfg_halves_as_two_lanes_are_bit_identical_to_one_stream(golden, precisi
         c.close()
 
 
-
-def test_resblock_partials_handed_to_groupnorm_are_bit_identical(golden):
-    """Round 5: a ResBlock's first convolution does not reduce its K slices -- the slices' partial sums go to the one-pass
-    GroupNorm that is their only reader (bias + time-embedding row added while it loads; no reduce launch, the fp32 tensor in
-    between never exists).  Same sums in the same order: the UNet's output equals the MAA_NO_PARTIALS=1 form bit for bit, in a
-    batch and alone; and the profile of the default form has fewer reduce launches."""
-    import os
-    from audiogpt_amd.backend import Context, UNet, reload_tuning
-    g = golden("unet_t2a")
-    x, t, c = torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"])
-    x, t, c = torch.cat([x, x.flip(0), x]), torch.cat([t, t.flip(0), t]), torch.cat([c, c.flip(0), c])
-    ctx = Context("cuda:0", precision="bf16x3")
-    u = UNet(ctx, C.UNET_T2A, WT.make_unet_state_dict(C.UNET_T2A, seed=0))
-    out, launches = {}, {}
-    try:
-        for mode in ("1", "0"):
-            os.environ["MAA_NO_PARTIALS"] = mode
-            reload_tuning()
-            ctx.prof_begin(detail=True)
-            out[mode] = u(x, t, c).cpu()
-            rows = ctx.prof_end()
-            launches[mode] = sum(v["launches"] for v in rows.values())
-        one = u(x[1:2], t[1:2], c[1:2]).cpu()
-    finally:
-        os.environ.pop("MAA_NO_PARTIALS", None)
-        reload_tuning()
-    assert torch.equal(out["0"], out["1"]) and torch.equal(one, out["0"][1:2])
-    check("unet_t2a_partials_vs_reference", out["0"][:g["y"].shape[0]], g["y"], 2e-4)
-    u.close()
-    ctx.close()
