@@ -36,6 +36,7 @@ struct FlashArgs {
     int ldo;
     int out_split;                // write split32 lines (the to_out projection reads them with no conversion)
     int causal;                   // query i sees keys 0 .. i only (OpenCLIP's text tower)
+    int qtiles, xcd_on;           // 128-query tiles per (sample, head); XCD-contiguous work order (maa_internal.h)
     long long o_bs;
     const float* zeros;
 };
@@ -77,8 +78,11 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int lq = lane & 31, lh = lane >> 5;
-    const int bh = blockIdx.y, b = bh / a.heads, h = bh - b * a.heads;
-    const int q0 = blockIdx.x * 128 + wid * 32;
+    // work item = ((sample, head), query tile), sample-major; XCD-contiguous: the workgroups of a sample share one XCD, where the
+    // q / k / v rows of that sample were written by the projection's tiles and its K / V tiles are fetched into L2 once
+    const int w = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, a.xcd_on);
+    const int bh = w / a.qtiles, b = bh / a.heads, h = bh - b * a.heads;
+    const int q0 = (w - bh * a.qtiles) * 128 + wid * 32;
     const bool wave_live = q0 < a.Nq;          // wave-uniform
     const float* qp = a.q + b * a.q_bs + h * a.hsq;
     const float* kp = a.k + b * a.k_bs + h * a.hsk;
@@ -361,7 +365,7 @@ void launch_dh(const Ctx& ctx, const FlashArgs& a, int B) {
     constexpr size_t lds = kv > tr ? kv : tr;
     auto kern = flash_attn_kernel<DH, TERMS>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
-    dim3 grid((unsigned)((a.Nq + 127) / 128), (unsigned)(B * a.heads));
+    dim3 grid((unsigned)(a.qtiles * B * a.heads));
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, a);
 }
 
@@ -402,6 +406,8 @@ bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, co
     a.causal = causal;
     a.o_bs = (long long)Nq * ldo;
     a.zeros = ctx.zeros;
+    a.qtiles = (Nq + 127) / 128;
+    a.xcd_on = ctx.tune.xcd_align ? 1 : 0;
     const double flops = 4.0 * B * heads * (double)Nq * Nk * dh;
     const double bytes = 4.0 * B * heads * ((double)2 * Nq * dh + 2.0 * Nk * dh);
     ProfScope prof(ctx, "flash_attention", flops, bytes);

@@ -352,11 +352,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
 // (j, j+1) -- of one tile, so every thread reads back exactly the registers its GEMM twin wrote.
 template <int JW>
 __global__ void splitk_reduce_kernel(const IGemm p, const float* __restrict__ part, int S, int tiles, int ntiles, int Nb,
-                                     int BM, int BN, int WGN, int MI, int NI) {
+                                     int BM, int BN, int WGN, int MI, int NI, int xcd_on) {
     const int NTH = blockDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int njb = NI / JW, nblk = MI * njb;
-    const int tile = blockIdx.x / nblk, blk = blockIdx.x - tile * nblk;
+    const int wi = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, xcd_on);      // the blocks of a tile, and neighbouring tiles' rows, on one XCD
+    const int tile = wi / nblk, blk = wi - tile * nblk;
     const int i = blk / njb, j = (blk - i * njb) * JW;
     const int mt = tile / ntiles, nt = tile - mt * ntiles;
     const int wm = wid / WGN, wn = wid - wm * WGN;
@@ -469,12 +470,12 @@ void launch_splitk_reduce(const Ctx& ctx, const IGemm& p, const float* part, int
                           int BN, int WGN, int MI, int NI, int NTH) {
     if (p.geglu && NI % 2 == 0) {
         hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)(tiles * MI * (NI / 2))), dim3(NTH), 0, ctx.stream, p, part, S,
-                           tiles, ntiles, Nb, BM, BN, WGN, MI, NI);
+                           tiles, ntiles, Nb, BM, BN, WGN, MI, NI, ctx.tune.xcd_align ? 1 : 0);
         return;
     }
     MAA_CHECK(!p.geglu, "split-K reduce: GEGLU needs value / gate block pairs inside a wave");
     hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)(tiles * MI * NI)), dim3(NTH), 0, ctx.stream, p, part, S, tiles,
-                       ntiles, Nb, BM, BN, WGN, MI, NI);
+                       ntiles, Nb, BM, BN, WGN, MI, NI, ctx.tune.xcd_align ? 1 : 0);
 }
 
 Dma2Plan igemm_dma2_plan(const Ctx& ctx, const IGemm& p) { return plan_impl(ctx, p); }

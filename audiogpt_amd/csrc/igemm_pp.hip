@@ -76,6 +76,8 @@ struct PPArgs {
     int nci, cps;        // channel chunks in all, per K slice
     int Nb;              // rows of the packed weight that exist
     float* part;         // split-K slabs or null
+    int S, tile_major;   // K slices; 1: the slices of a tile are neighbours in the item order (one XCD writes a tile's slabs, the XCD
+                         // whose reduce blocks read them and whose rows the consumer reads: xcd_contiguous, maa_internal.h), 0: slice-major
     int dbg;             // TUNE instantiation only (MAA_PP_DBG): 1 no MFMAs, 2 no copies after the prologue, 4 no fragment reads, 8 no vmcnt wait
 };
 
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     const int TAPS = q.T;
     const int W = q.W, H = q.H;
     const long long Mtot = p.M;
-    int item = 0, m0 = 0, n0 = 0, c_begin = 0, c_end = 0, NQ = 0;
+    int item = 0, m0 = 0, n0 = 0, c_begin = 0, c_end = 0, NQ = 0, cur_slab = 0;
 
     // zero line (read by lanes whose tap is outside the image)
     if (tid < 8) *reinterpret_cast<f32x4*>(sZ + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -166,7 +168,9 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     auto setup_item = [&](int w) __attribute__((always_inline)) {
         item = w_lo + w;
         // (the quotients are wave-uniform but come out of the VALU's division sequence: back into SGPRs)
-        const int slice = __builtin_amdgcn_readfirstlane(item / q.tiles), tile = item - slice * q.tiles;
+        const int slice = __builtin_amdgcn_readfirstlane(q.tile_major ? item % q.S : item / q.tiles);
+        const int tile = __builtin_amdgcn_readfirstlane(q.tile_major ? item / q.S : item - slice * q.tiles);
+        cur_slab = slice * q.tiles + tile;
         const int mt = __builtin_amdgcn_readfirstlane(tile / q.ntiles), nt = tile - mt * q.ntiles;
         m0 = mt * BM;
         n0 = nt * BN;
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         }
         // Every fragment read of this item is done (a wave gets here through the barrier that follows group 1's last memory
         // phase): the next item's first copies may overwrite the rings while this item's results are stored.
-        const int e_item = item, e_m0 = m0, e_n0 = n0;
+        const int e_slab = cur_slab, e_m0 = m0, e_n0 = n0;
         const int w_next = w_cur + w_step;
         bool more = false;
         if constexpr (PERSIST) {
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
             igemm_epilogue<MI, NI>(p, acc, row_base, col_base, lrow, lk, 0, q.Nb, rpb);
         } else {
             // slab of this (slice, tile): [MI NI blocks][4 register quads][512 threads][4 floats]
-            float* pp = q.part + ((long long)e_item * (MI * NI * 4) * 512 + tid) * 4;
+            float* pp = q.part + ((long long)e_slab * (MI * NI * 4) * 512 + tid) * 4;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -492,6 +496,8 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     q.cps = (q.nci + pl.S - 1) / pl.S;
     q.Nb = Nb;
     q.part = pl.S > 1 ? part : nullptr;
+    q.S = pl.S;
+    q.tile_major = ctx.tune.xcd_align && pl.S > 1 ? 1 : 0;
     q.dbg = ctx.tune.pp_dbg >= 0 ? ctx.tune.pp_dbg : 0;
     MAA_CHECK((q.nci + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
     MAA_CHECK(q.CAPl > 0, "igemm_pp: the A ring does not fit beside the weight ring");

@@ -82,6 +82,19 @@ struct ProfScope {     // records an event pair around the launches issued durin
     size_t idx_ = 0;
 };
 
+// XCD-contiguous work order (device code).  Workgroup `bid` of a 1-D grid of `n` runs on XCD bid % 8 (observed placement, used for
+// speed only: MI355X_MICROARCH.md); XCD x takes the x-th contiguous eighth of the work items, workgroup by workgroup -- the order every
+// implicit-GEMM engine gives its tiles (M-major), so that the rows a workgroup of a normalisation / attention / reduce launch reads
+// were written, and the rows it writes will be read, by workgroups of the SAME XCD: its L2 (4 MB, not shared between XCDs) instead
+// of the fabric.  `on` = 0: the identity (A/B).
+#if defined(__HIPCC__)
+__device__ __forceinline__ int xcd_contiguous(int bid, int n, int on) {
+    if (!on) return bid;
+    const int xcd = bid & 7, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+#endif
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); safe from several launching threads
 void ensure_dynamic_lds(const void* kernel, int device, int bytes);
 int device_cu_count(int device);      // multiProcessorCount, cached per device
@@ -124,6 +137,7 @@ struct Tuning {
     bool no_dma = false;                    // MAA_NO_DMA: every bf16 contraction on the register-staged engine (bit-identity tests)
     bool no_halo = false;                   // MAA_NO_HALO: the narrow vocoder stages through the implicit GEMM (bit-identity test)
     bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
+    bool xcd_align = true;                  // MAA_XCD_ALIGN=0: normalisation / attention / reduce workgroups in plain blockIdx order (A/B of xcd_contiguous)
     bool gn_two_pass = false;               // MAA_GN_TWO_PASS=1: GroupNorm as the statistics + apply launches of rounds 1-4 everywhere (A/B, tests)
     bool cfg_split = true;                  // MAA_CFG_SPLIT=0: the two halves of a classifier-free-guidance step one after the other on one stream
     void load();

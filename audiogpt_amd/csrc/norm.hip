@@ -174,11 +174,14 @@ __global__ __launch_bounds__(1024) void gn_fused_kernel(const float* __restrict_
                                                         const float* __restrict__ x2, int ld2, int C2, int HW, int groups,
                                                         int GPB, float eps, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int silu, float* __restrict__ out,
-                                                        int split, float* __restrict__ raw_split) {
+                                                        int split, float* __restrict__ raw_split, int nblk, int xcd_on) {
     extern __shared__ float gsm[];      // red[RL Q 8] | colsum[2 CB] | gstat[2 GPB]
     const int C = C1 + C2, cpg = C / groups, CB = GPB * cpg, Q = CB >> 2;
     const int RL = (int)blockDim.x / Q;                      // (blockDim.x == RL Q)
-    const int b = blockIdx.y, c_lo = blockIdx.x * CB;
+    // work item = (sample, group block), sample-major; XCD-contiguous: a sample's rows are read and written on the XCD whose
+    // igemm tiles produce / consume them
+    const int w = xcd_contiguous((int)blockIdx.x, (int)gridDim.x, xcd_on);
+    const int b = w / nblk, c_lo = (w - b * nblk) * CB;
     const int t = threadIdx.x, ty = t / Q, tx = t - ty * Q;
     const int c = c_lo + 4 * tx;
     float* const red = gsm;
@@ -321,9 +324,9 @@ template <int NR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long rows, int C,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        float* __restrict__ out, int split) {
+                                                        float* __restrict__ out, int split, int xcd_on) {
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long row = (long long)xcd_contiguous((int)blockIdx.x, (int)gridDim.x, xcd_on) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* src = x + row * C;
     float4 v[NR];
@@ -476,10 +479,11 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
     ProfScope prof(ctx, "groupnorm", 0.0, 8.0 * B * (double)HW * C);
     const GnFusedPlan fp = ctx.tune.gn_two_pass ? GnFusedPlan() : gn_fused_plan(C, C1, HW, groups);
     if (fp.gpb) {
-        dim3 grid((unsigned)(groups / fp.gpb), (unsigned)B);
+        const int nblk = groups / fp.gpb;
+        dim3 grid((unsigned)(nblk * B));
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, grid, dim3((unsigned)fp.threads), fp.lds, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW, groups, fp.gpb, eps,
-                               gamma, beta, silu, out, out_split, raw_split);
+                               gamma, beta, silu, out, out_split, raw_split, nblk, ctx.tune.xcd_align ? 1 : 0);
         };
         switch (fp.nr) {
             case 1: go(gn_fused_kernel<1>); break;
@@ -508,14 +512,15 @@ void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, con
     MAA_CHECK(C <= 2048 && C % 4 == 0, "layernorm width");
     ProfScope prof(ctx, "layernorm", 0.0, 8.0 * rows * (double)C);
     dim3 grid((unsigned)((rows + 3) / 4));
+    const int xa = ctx.tune.xcd_align ? 1 : 0;
     if (C <= 256)
-        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
+        hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split, xa);
     else if (C <= 512)
-        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
+        hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split, xa);
     else if (C <= 1024)
-        hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
+        hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split, xa);
     else      // the ViT-H image tower's 1280-wide rows
-        hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split);
+        hipLaunchKernelGGL(layernorm_kernel<8>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split, xa);
     MAA_HIP(hipGetLastError());
 }
 

@@ -252,3 +252,30 @@ def test_cfg_halves_as_two_lanes_are_bit_identical_to_one_stream(golden, precisi
         c.close()
 
 
+
+
+def test_xcd_contiguous_work_order_does_not_change_results(golden):
+    """Round 5: the workgroups of the one-pass GroupNorm, LayerNorm, flash attention and the split-K reduce take their work items in
+    XCD-contiguous order (a sample's rows are read and written on the XCD whose igemm tiles produce / consume them) and the K
+    slices of a convolution tile are neighbours in the item order.  Scheduling only: the UNet's output equals the MAA_XCD_ALIGN=0
+    form bit for bit."""
+    import os
+    from audiogpt_amd.backend import Context, UNet, reload_tuning
+    g = golden("unet_t2a")
+    x, t, c = torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"])
+    x, t, c = torch.cat([x, x.flip(0), x]), torch.cat([t, t.flip(0), t]), torch.cat([c, c.flip(0), c])
+    ctx = Context("cuda:0", precision="bf16x3")
+    u = UNet(ctx, C.UNET_T2A, WT.make_unet_state_dict(C.UNET_T2A, seed=0))
+    out = {}
+    try:
+        for mode in ("0", "1"):
+            os.environ["MAA_XCD_ALIGN"] = mode
+            reload_tuning()
+            out[mode] = u(x, t, c).cpu()
+    finally:
+        os.environ.pop("MAA_XCD_ALIGN", None)
+        reload_tuning()
+    assert torch.equal(out["0"], out["1"])
+    check("unet_t2a_xcd_aligned_vs_reference", out["1"][:g["y"].shape[0]], g["y"], 2e-4)
+    u.close()
+    ctx.close()
