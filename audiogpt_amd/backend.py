@@ -340,13 +340,22 @@ class UNet:
         logs = None
         if log_every_t is not None:
             n_log = sum(1 for i in range(S) if i % int(log_every_t) == 0 or i == S - 1)
-            logs = (torch.empty(n_log, B, Cc, H, W, device=dev), torch.empty(n_log, B, Cc, H, W, device=dev))
+            # the log slabs are part of the captured step (their addresses are in the step graph's key, csrc/ddim.cpp): one pair
+            # per shape is kept by this model and the caller gets copies, so that a second sample() call replays the kept graph
+            # whatever the caching allocator would have handed out for fresh tensors
+            cache = self.__dict__.setdefault("_log_slabs", {})
+            key = (n_log, B, Cc, H, W)
+            if key not in cache:
+                if len(cache) >= 4:
+                    cache.clear()
+                cache[key] = (torch.empty(n_log, B, Cc, H, W, device=dev), torch.empty(n_log, B, Cc, H, W, device=dev))
+            logs = cache[key]
             a.log_every_t, a.n_log = int(log_every_t), n_log
             a.d_log_x, a.d_log_x0 = logs[0].data_ptr(), logs[1].data_ptr()
         with self.ctx.lock:
             L.check(self.ctx.lib.maa_ddim_sample(self.ctx.h, self.h, C.byref(a), L.dptr(x)))
         if logs is not None:
-            return x, logs[0], logs[1]
+            return x, logs[0].clone(), logs[1].clone()
         return x
 
     def close(self):

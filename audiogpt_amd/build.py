@@ -17,6 +17,12 @@ SOURCES = ["igemm_f32.hip", "igemm_bf16.hip", "igemm_dma.hip", "igemm_dma2.hip",
            "vocoder.cpp", "diffnet.cpp", "encoders.cpp", "clap_audio.cpp", "ddim.cpp", "api.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+LINK = []
+if os.environ.get("MAA_BUILD_ROCTX") == "1":      # per-DDIM-step roctx ranges (csrc/ddim.cpp) for rocprofv3 --marker-trace
+    FLAGS = FLAGS + ["-DMAA_ROCTX"]
+    LINK = ["-L/opt/rocm/lib", "-lroctx64"]
+if os.environ.get("MAA_BUILD_NO_TUNING") == "1":  # deployment build: the MAA_* test / A-B switches are compiled out (runtime.cpp)
+    FLAGS = FLAGS + ["-DMAA_NO_TUNING"]
 
 
 def _hipcc():
@@ -79,7 +85,7 @@ def build(force=False, verbose=True):
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(bdir, s + ".o") for s in SOURCES]
     if jobs or not os.path.exists(OUT):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + LINK
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-8000:])

@@ -14,7 +14,19 @@
 #include "models.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+
+// Per-DDIM-step range markers for rocprofv3 --marker-trace (tracing): compiled in by
+// `MAA_BUILD_ROCTX=1 python -m audiogpt_amd.build --force` (-DMAA_ROCTX, links libroctx64); the default build has none.
+#ifdef MAA_ROCTX
+#include <roctracer/roctx.h>
+#define MAA_RANGE_PUSH(name) roctxRangePushA(name)
+#define MAA_RANGE_POP() roctxRangePop()
+#else
+#define MAA_RANGE_PUSH(name) ((void)0)
+#define MAA_RANGE_POP() ((void)0)
+#endif
 
 namespace maa {
 
@@ -177,10 +189,16 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
         }
     }
     for (int i = first; i < a.S; ++i) {
+#ifdef MAA_ROCTX
+        char range[48];
+        std::snprintf(range, sizeof(range), "ddim_step %d/%d t=%d", i + 1, a.S, (int)a.h_timesteps[a.S - 1 - i]);
+#endif
+        MAA_RANGE_PUSH(range);
         if (a.use_graph)
             MAA_HIP(hipGraphLaunch(sg.exec, ctx.stream));
         else
             step_body();
+        MAA_RANGE_POP();
     }
     MAA_HIP(hipMemcpyAsync(d_x, xs, (size_t)a.B * per * 4, hipMemcpyDeviceToDevice, ctx.stream));
     MAA_HIP(hipStreamSynchronize(ctx.stream));   // the host tables go out of scope; the call returns a finished latent

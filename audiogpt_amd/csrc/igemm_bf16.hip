@@ -407,7 +407,8 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         cfg = choose_tile(p.M, ncols, p.Z, true);
     }
     const bool no_dma = ctx.tune.no_dma;      // tests: same arithmetic, register staging
-    const bool dma = terms == 3 && p.a_split && p.b_split && cfg < 3 && !no_dma;
+    // both bf16 modes: split32 x split32 problems go to the LDS-DMA engines (TERMS = 1: the hi halves are the bf16 operands)
+    const bool dma = p.a_split && p.b_split && cfg < 3 && !no_dma;
     const PPPlan planp = dma ? igemm_pp_plan(ctx, p) : PPPlan();
     if (planp.bn) {
         // halo-staged ping-pong engine for the 3x3 convolutions (igemm_pp.hip); slabs borrowed like the second engine's
@@ -416,7 +417,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         float* part = nf ? ctx.ws.alloc_f(nf) : nullptr;
         if (!ctx.ws.dry) {
             char shapep[64];
-            const char* namep = igemm_pp_name(planp);
+            const char* namep = igemm_pp_name(planp, terms);
             if (ctx.prof && ctx.prof->detail) {
                 std::snprintf(shapep, sizeof(shapep), "pp%d M%d N%d K%d S%d", planp.bn, p.M, ncols, p.K, planp.S);
                 namep = shapep;
@@ -435,7 +436,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         float* part = nf ? ctx.ws.alloc_f(nf) : nullptr;
         if (!ctx.ws.dry) {
             char shapeq[64];
-            const char* nameq = igemm_pp1_name(planq);
+            const char* nameq = igemm_pp1_name(planq, terms);
             if (ctx.prof && ctx.prof->detail) {
                 std::snprintf(shapeq, sizeof(shapeq), "pq%d M%d N%d K%d S%d", planq.bn, p.M, ncols, p.K, planq.S);
                 nameq = shapeq;
@@ -458,7 +459,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
             const double flops2 = 2.0 * p.M * (double)ncols * p.K;
             const double bytes2 = 4.0 * ((double)p.K * ncols + (double)p.M * p.N);
             char shape2[64];
-            const char* name2 = igemm_dma2_name(plan2);
+            const char* name2 = igemm_dma2_name(plan2, terms);
             if (ctx.prof && ctx.prof->detail) {
                 std::snprintf(shape2, sizeof(shape2), "b2 M%d N%d K%d t%d", p.M, ncols, p.K, taps);
                 name2 = shape2;
@@ -475,10 +476,11 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
     const double flops = 2.0 * p.M * (double)ncols * p.K * p.Z;
     const double bytes = 4.0 * ((double)p.K * ncols + (double)p.M * p.N * p.Z);
     static const char* kNamesD[3] = {"igemm_dma_bf16x3<128x128>", "igemm_dma_bf16x3<128x64>", "igemm_dma_bf16x3<64x64>"};
+    static const char* kNamesD1[3] = {"igemm_dma_bf16<128x128>", "igemm_dma_bf16<128x64>", "igemm_dma_bf16<64x64>"};
     static const char* kNames3[5] = {"igemm_bf16x3<128x128>", "igemm_bf16x3<128x64>", "igemm_bf16x3<64x64>", "igemm_bf16x3<256x32>", "igemm_bf16x3<128x32>"};
     static const char* kNames1[5] = {"igemm_bf16<128x128>", "igemm_bf16<128x64>", "igemm_bf16<64x64>", "igemm_bf16<256x32>", "igemm_bf16<128x32>"};
     char shape_name[48];
-    const char* pname = dma ? kNamesD[cfg] : terms == 3 ? kNames3[cfg] : kNames1[cfg];
+    const char* pname = dma ? (terms == 3 ? kNamesD[cfg] : kNamesD1[cfg]) : terms == 3 ? kNames3[cfg] : kNames1[cfg];
     if (ctx.prof && ctx.prof->detail) {
         std::snprintf(shape_name, sizeof(shape_name), "b%c%d M%d N%d K%d t%d Z%d", dma ? 'd' : 'g', cfg, p.M, ncols, p.K, taps, p.Z);
         pname = shape_name;

@@ -41,7 +41,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int BM, int BN, int WGM, int WGN, int NS>
+// TERMS = 3: bf16x3 (lo.hi, hi.lo, hi.hi); TERMS = 1: the context's plain-bf16 mode -- the operands are the hi halves of the
+// same split32 lines (hi = bf16(x) is exactly the rounding that mode asks for), one MFMA per k-step, the lo halves are never read
+template <int BM, int BN, int WGM, int WGN, int NS, int TERMS>
 __global__ __launch_bounds__(NT) void igemm_dma_kernel(const IGemm p, int ntiles, int Nb) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int MI = WTM / 32, NI = WTN / 32;
@@ -179,27 +181,31 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const IGemm p, int ntiles
             for (int g = 0; g < G; ++g) {
                 const int ks = k0 + g;
 #pragma unroll
-                for (int i = 0; i < MI; ++i) al[g][i] = *reinterpret_cast<const bf16x8*>(base + a_row + i * 4096 + slot_off[1][ks]);
+                for (int i = 0; i < MI; ++i)
+                    if constexpr (TERMS == 3) al[g][i] = *reinterpret_cast<const bf16x8*>(base + a_row + i * 4096 + slot_off[1][ks]);
 #pragma unroll
                 for (int j = 0; j < NI; ++j) bh[g][j] = *reinterpret_cast<const bf16x8*>(base + b_row + j * 4096 + slot_off[0][ks]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) ah[g][i] = *reinterpret_cast<const bf16x8*>(base + a_row + i * 4096 + slot_off[0][ks]);
 #pragma unroll
-                for (int j = 0; j < NI; ++j) bl[g][j] = *reinterpret_cast<const bf16x8*>(base + b_row + j * 4096 + slot_off[1][ks]);
+                for (int j = 0; j < NI; ++j)
+                    if constexpr (TERMS == 3) bl[g][j] = *reinterpret_cast<const bf16x8*>(base + b_row + j * 4096 + slot_off[1][ks]);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
+                if constexpr (TERMS == 3) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g][i], bh[g][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g][i], bh[g][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g][i], bl[g][j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g][i], bl[g][j], acc[i][j], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -230,15 +236,23 @@ __global__ __launch_bounds__(NT) void igemm_dma_kernel(const IGemm p, int ntiles
     igemm_epilogue<MI, NI>(p, acc, m0 + wm * WTM, n0 + wn * WTN, lrow, lk, 0, Nb, rpb);
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS>
-void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
+template <int BM, int BN, int WGM, int WGN, int NS, int TERMS>
+void launch_terms(const Ctx& ctx, const IGemm& p, int Nb) {
     const int ncols = p.N * (p.geglu ? 2 : 1);
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (ncols + BN - 1) / BN;
     dim3 grid((unsigned)((long long)mtiles * ntiles));
     constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
-    auto kern = igemm_dma_kernel<BM, BN, WGM, WGN, NS>;
+    auto kern = igemm_dma_kernel<BM, BN, WGM, WGN, NS, TERMS>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, p, ntiles, Nb);
+}
+
+template <int BM, int BN, int WGM, int WGN, int NS>
+void launch_one(const Ctx& ctx, const IGemm& p, int Nb) {
+    if (ctx.dtype == 2)
+        launch_terms<BM, BN, WGM, WGN, NS, 1>(ctx, p, Nb);
+    else
+        launch_terms<BM, BN, WGM, WGN, NS, 3>(ctx, p, Nb);
 }
 
 }  // namespace

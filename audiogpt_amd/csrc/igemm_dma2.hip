@@ -63,7 +63,8 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NS>
+// TERMS: 3 = bf16x3; 1 = the context's plain-bf16 mode (operands = the hi halves of the same split32 lines, one MFMA per k-step)
+template <int BM, int BN, int WGM, int WGN, int NS, int TERMS>
 __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm p, int ntiles, int tiles, int Nb,
                                                                      int cps, int items, float* __restrict__ part) {
     constexpr int NW = WGM * WGN, NTH = 64 * NW;
@@ -235,24 +236,28 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
     };
     auto read_frags = [&](const char* base, int ks, Frags& f) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) f.al[i] = *reinterpret_cast<const bf16x8*>(base + a_row + i * 4096 + slot_off[1][ks]);
+        for (int i = 0; i < MI; ++i)
+            if constexpr (TERMS == 3) f.al[i] = *reinterpret_cast<const bf16x8*>(base + a_row + i * 4096 + slot_off[1][ks]);
 #pragma unroll
         for (int j = 0; j < NI; ++j) f.bh[j] = *reinterpret_cast<const bf16x8*>(base + b_row + j * 4096 + slot_off[0][ks]);
 #pragma unroll
         for (int i = 0; i < MI; ++i) f.ah[i] = *reinterpret_cast<const bf16x8*>(base + a_row + i * 4096 + slot_off[0][ks]);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) f.bl[j] = *reinterpret_cast<const bf16x8*>(base + b_row + j * 4096 + slot_off[1][ks]);
+        for (int j = 0; j < NI; ++j)
+            if constexpr (TERMS == 3) f.bl[j] = *reinterpret_cast<const bf16x8*>(base + b_row + j * 4096 + slot_off[1][ks]);
     };
     // the 3 MI NI MFMAs of one k-step; term-major, so the three products of an accumulator are MI NI - 1 MFMAs apart
     auto mma = [&](const Frags& f) __attribute__((always_inline)) {
+        if constexpr (TERMS == 3) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -324,9 +329,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
             read_frags(smem + st_next * STAGE, 0, f0);      // (past the last chunk: zeros, never multiplied)
             __builtin_amdgcn_sched_barrier(0);
             // MFMAs of k-step 1 interleaved with the IPW copies
-            static_for<0, 3 * MI * NI>([&](auto xc) {
+            static_for<0, TERMS * MI * NI>([&](auto xc) {
                 constexpr int x = decltype(xc)::value;
-                constexpr int t = x / (MI * NI), i = (x % (MI * NI)) / NI, j = x % NI;
+                constexpr int t = x / (MI * NI) + (3 - TERMS), i = (x % (MI * NI)) / NI, j = x % NI;
                 if constexpr (t == 0)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.al[i], f1.bh[j], acc[i][j], 0, 0, 0);
                 else if constexpr (t == 1)
@@ -336,8 +341,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void igemm_dma2_kernel(const IGemm 
                 if constexpr (x < IPW) copy1(st_fill, xc);
                 __builtin_amdgcn_sched_barrier(0);
             });
-            if constexpr (IPW > 3 * MI * NI)          // (small tiles: more copies than MFMAs to carry them)
-                static_for<3 * MI * NI, IPW>([&](auto jc) { copy1(st_fill, jc); });
+            if constexpr (IPW > TERMS * MI * NI)          // (small tiles, one term: more copies than MFMAs to carry them)
+                static_for<TERMS * MI * NI, IPW>([&](auto jc) { copy1(st_fill, jc); });
             advance();
             st = st_next;
             if (--c_rem == 0)
@@ -402,8 +407,6 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
     MAA_CHECK(!p.geglu || NI % 2 == 0, "GEGLU needs value / gate block pairs inside a wave");
     constexpr size_t lds = (size_t)NS * (BM + BN) * 128;
     static_assert(lds <= 163840, "LDS per workgroup");
-    auto kern = igemm_dma2_kernel<BM, BN, WGM, WGN, NS>;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     const long long items = (long long)tiles * S;
     long long grid = items;
     if (ctx.tune.dma2_persist) {
@@ -411,8 +414,15 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
         const long long cap = (long long)cu_count(ctx) * (per_cu < 1 ? 1 : per_cu);
         if (grid > cap) grid = cap;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTH), lds, ctx.stream, p, ntiles, tiles, Nb, cps, (int)items,
-                       S > 1 ? part : nullptr);
+    auto go = [&](auto kern) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTH), lds, ctx.stream, p, ntiles, tiles, Nb, cps, (int)items,
+                           S > 1 ? part : nullptr);
+    };
+    if (ctx.dtype == 2)
+        go(igemm_dma2_kernel<BM, BN, WGM, WGN, NS, 1>);
+    else
+        go(igemm_dma2_kernel<BM, BN, WGM, WGN, NS, 3>);
     if (S > 1) launch_splitk_reduce(ctx, p, part, S, tiles, ntiles, Nb, BM, BN, WGN, MI, NI, NTH);
 }
 
@@ -487,7 +497,10 @@ size_t igemm_dma2_workspace_floats(const IGemm& p, const Dma2Plan& pl) {
     return (size_t)(tiles * pl.S * 128 * 128);
 }
 
-const char* igemm_dma2_name(const Dma2Plan& pl) { return pl.S > 1 ? "igemm_dma2_bf16x3<128x128,splitK>" : "igemm_dma2_bf16x3<128x128>"; }
+const char* igemm_dma2_name(const Dma2Plan& pl, int terms) {
+    if (terms == 1) return pl.S > 1 ? "igemm_dma2_bf16<128x128,splitK>" : "igemm_dma2_bf16<128x128>";
+    return pl.S > 1 ? "igemm_dma2_bf16x3<128x128,splitK>" : "igemm_dma2_bf16x3<128x128>";
+}
 
 // The caller has checked the split32 conditions (both operands split, single source, C % 32 == 0, K % 32 == 0, 16-byte
 // aligned rows, Z == 1, no A activation) and provides `part` = igemm_dma2_workspace_floats() floats when that is > 0.

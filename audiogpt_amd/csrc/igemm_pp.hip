@@ -89,7 +89,9 @@ struct PPArgs {
 // OUT: 0 = the result leaves through the fused epilogue or as a split-K slab (run-time choice; the TUNE build), 1 = epilogue
 // only, 2 = slab only -- the UNet's launches are all of the last kind, and an instantiation without the epilogue's registers
 // has no scratch at all
-template <int MI, int NI, int GWM, int GWN, int NPA, bool TUNE, bool PERSIST, int OUT>
+// TERMS: 3 = bf16x3; 1 = the context's plain-bf16 mode: the hi halves of the same split32 lines are the operands (one MFMA per
+// k-step, the lo halves are staged with their lines but never read) -- the same schedule, a third of the matrix phase
+template <int MI, int NI, int GWM, int GWN, int NPA, bool TUNE, bool PERSIST, int OUT, int TERMS>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPArgs q) {
     constexpr int BN = GWN * NI * 32;
     constexpr int BPG = BN / 16;                    // weight pieces (8 rows x 128 B) per group and chunk: half a chunk
@@ -250,8 +252,10 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
             const unsigned base = ok ? line * 128u : zaddr;
             ah[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x00u ^ t1)));
             ah[1][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x20u ^ t1)));
-            al[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x40u ^ t1)));
-            al[1][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x60u ^ t1)));
+            if constexpr (TERMS == 3) {
+                al[0][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x40u ^ t1)));
+                al[1][i] = *reinterpret_cast<const bf16x8*>(smem + (base + (0x60u ^ t1)));
+            }
         }
         const char* const bs = sB + slot * (BN * 128);
 #pragma unroll
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bh[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[0][ks]);
-                bl[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[1][ks]);
+                if constexpr (TERMS == 3) bl[ks][jn] = *reinterpret_cast<const bf16x8*>(bs + jn * 4096 + b_off[1][ks]);
             }
         }
     };
@@ -323,16 +327,18 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     auto mma_phase = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if constexpr (TERMS == 3) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int jn = 0; jn < NI; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][jn], acc[i][jn], 0, 0, 0);
+                    for (int jn = 0; jn < NI; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][jn], acc[i][jn], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int jn = 0; jn < NI; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][jn], acc[i][jn], 0, 0, 0);
+                    for (int jn = 0; jn < NI; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][jn], acc[i][jn], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -451,10 +457,10 @@ int pp_ring_lines(const PPGeom& g, int bn) {
     return cap <= room ? cap : 0;
 }
 
-template <int MI, int NI, int GWM, int GWN, int NPA>
-void launch_npa(const Ctx& ctx, const IGemm& p, const PPArgs& q, int items, size_t lds) {
-    if (ctx.tune.pp_dbg >= 0) {      // timing ablations (MAA_PP_DBG): a separate instantiation, never the product's
-        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, NPA, true, true, 0>;
+template <int MI, int NI, int GWM, int GWN, int NPA, int TERMS>
+void launch_npa_terms(const Ctx& ctx, const IGemm& p, const PPArgs& q, int items, size_t lds) {
+    if (TERMS == 3 && ctx.tune.pp_dbg >= 0) {      // timing ablations (MAA_PP_DBG): a separate instantiation, never the product's
+        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, NPA, true, true, 0, 3>;
         ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
         hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
         return;
@@ -464,10 +470,18 @@ void launch_npa(const Ctx& ctx, const IGemm& p, const PPArgs& q, int items, size
         hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
     };
     const bool persist = q.items > items, slab = q.part != nullptr;      // (more items than workgroups: persistent)
-    if (persist && slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 2>);
-    else if (persist) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 1>);
-    else if (slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, false, 2>);
-    else go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, false, 1>);
+    if (persist && slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 2, TERMS>);
+    else if (persist) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, true, 1, TERMS>);
+    else if (slab) go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, false, 2, TERMS>);
+    else go(igemm_pp_kernel<MI, NI, GWM, GWN, NPA, false, false, 1, TERMS>);
+}
+
+template <int MI, int NI, int GWM, int GWN, int NPA>
+void launch_npa(const Ctx& ctx, const IGemm& p, const PPArgs& q, int items, size_t lds) {
+    if (ctx.dtype == 2)
+        launch_npa_terms<MI, NI, GWM, GWN, NPA, 1>(ctx, p, q, items, lds);
+    else
+        launch_npa_terms<MI, NI, GWM, GWN, NPA, 3>(ctx, p, q, items, lds);
 }
 
 template <int MI, int NI, int GWM, int GWN>
@@ -527,7 +541,7 @@ struct PP1Args {
     float* part;
 };
 
-template <int MI, int NI, int GWM, int GWN>
+template <int MI, int NI, int GWM, int GWN, int TERMS>
 __global__ __launch_bounds__(512) void igemm_pp1_kernel(const IGemm p, const PP1Args q) {
     constexpr int BN = GWN * NI * 32;
     constexpr int BPG = BN / 16;                    // weight pieces per group and chunk
@@ -626,14 +640,14 @@ __global__ __launch_bounds__(512) void igemm_pp1_kernel(const IGemm p, const PP1
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 ah[ks][i] = *reinterpret_cast<const bf16x8*>(st + a_row + i * 4096 + s_off[0][ks]);
-                al[ks][i] = *reinterpret_cast<const bf16x8*>(st + a_row + i * 4096 + s_off[1][ks]);
+                if constexpr (TERMS == 3) al[ks][i] = *reinterpret_cast<const bf16x8*>(st + a_row + i * 4096 + s_off[1][ks]);
             }
 #pragma unroll
         for (int jn = 0; jn < NI; ++jn)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bh[ks][jn] = *reinterpret_cast<const bf16x8*>(st + b_row + jn * 4096 + s_off[0][ks]);
-                bl[ks][jn] = *reinterpret_cast<const bf16x8*>(st + b_row + jn * 4096 + s_off[1][ks]);
+                if constexpr (TERMS == 3) bl[ks][jn] = *reinterpret_cast<const bf16x8*>(st + b_row + jn * 4096 + s_off[1][ks]);
             }
         int slot2 = slot + (NSB - 1);
         if (slot2 >= NSB) slot2 -= NSB;
@@ -644,16 +658,18 @@ __global__ __launch_bounds__(512) void igemm_pp1_kernel(const IGemm p, const PP1
     auto mma_phase = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if constexpr (TERMS == 3) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int jn = 0; jn < NI; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][jn], acc[i][jn], 0, 0, 0);
+                    for (int jn = 0; jn < NI; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][jn], acc[i][jn], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int jn = 0; jn < NI; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][jn], acc[i][jn], 0, 0, 0);
+                    for (int jn = 0; jn < NI; ++jn)
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][jn], acc[i][jn], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -715,10 +731,15 @@ void launch_one1(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float
     MAA_CHECK(!p.geglu || NI % 2 == 0, "GEGLU needs value / gate block pairs inside a wave");
     constexpr size_t lds = (size_t)NSB * (BM + BN) * 128 + 1024;
     static_assert(lds <= 163840, "LDS per workgroup");
-    auto kern = igemm_pp1_kernel<MI, NI, GWM, GWN>;
-    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     const int items = q.tiles * pl.S;
-    hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
+    auto go = [&](auto kern) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
+    };
+    if (ctx.dtype == 2)
+        go(igemm_pp1_kernel<MI, NI, GWM, GWN, 1>);
+    else
+        go(igemm_pp1_kernel<MI, NI, GWM, GWN, 3>);
     if (pl.S > 1) launch_splitk_reduce(ctx, p, part, pl.S, q.tiles, ntiles, Nb, BM, BN, GWN, MI, NI, 512);
 }
 }  // namespace
@@ -781,7 +802,11 @@ size_t igemm_pp_workspace_floats(const IGemm& p, const PPPlan& pl) {
     return (size_t)(tiles * pl.S * BM * pl.bn);
 }
 
-const char* igemm_pp_name(const PPPlan& pl) {
+const char* igemm_pp_name(const PPPlan& pl, int terms) {
+    if (terms == 1) {
+        if (pl.bn == 160) return pl.S > 1 ? "igemm_pp_bf16<256x160,splitK>" : "igemm_pp_bf16<256x160>";
+        return pl.S > 1 ? "igemm_pp_bf16<256x128,splitK>" : "igemm_pp_bf16<256x128>";
+    }
     if (pl.bn == 160) return pl.S > 1 ? "igemm_pp_bf16x3<256x160,splitK>" : "igemm_pp_bf16x3<256x160>";
     return pl.S > 1 ? "igemm_pp_bf16x3<256x128,splitK>" : "igemm_pp_bf16x3<256x128>";
 }
@@ -839,7 +864,11 @@ size_t igemm_pp1_workspace_floats(const IGemm& p, const PPPlan& pl) {
     return (size_t)(tiles * pl.S * BM * pl.bn);
 }
 
-const char* igemm_pp1_name(const PPPlan& pl) {
+const char* igemm_pp1_name(const PPPlan& pl, int terms) {
+    if (terms == 1) {
+        if (pl.bn == 160) return pl.S > 1 ? "igemm_pp1_bf16<256x160,splitK>" : "igemm_pp1_bf16<256x160>";
+        return pl.S > 1 ? "igemm_pp1_bf16<256x128,splitK>" : "igemm_pp1_bf16<256x128>";
+    }
     if (pl.bn == 160) return pl.S > 1 ? "igemm_pp1_bf16x3<256x160,splitK>" : "igemm_pp1_bf16x3<256x160>";
     return pl.S > 1 ? "igemm_pp1_bf16x3<256x128,splitK>" : "igemm_pp1_bf16x3<256x128>";
 }

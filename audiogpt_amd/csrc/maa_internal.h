@@ -236,7 +236,7 @@ struct Dma2Plan {
 };
 Dma2Plan igemm_dma2_plan(const Ctx& ctx, const IGemm& p);
 size_t igemm_dma2_workspace_floats(const IGemm& p, const Dma2Plan& pl);      // 0: no split-K for this problem
-const char* igemm_dma2_name(const Dma2Plan& pl);
+const char* igemm_dma2_name(const Dma2Plan& pl, int terms);
 void launch_igemm_dma2(const Ctx& ctx, const IGemm& p, int Nb, const Dma2Plan& pl, float* part);
 
 // adds the S slabs a split-K engine wrote in fragment order ([slice][tile][MI NI blocks][4 quads][NTH threads][4 floats]) in
@@ -250,12 +250,12 @@ struct PPPlan {
 };
 PPPlan igemm_pp_plan(const Ctx& ctx, const IGemm& p);
 size_t igemm_pp_workspace_floats(const IGemm& p, const PPPlan& pl);
-const char* igemm_pp_name(const PPPlan& pl);
+const char* igemm_pp_name(const PPPlan& pl, int terms);
 void launch_igemm_pp(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part);
 // ... and its 1x1 / Linear form (no halo; A and the weights share one ring)
 PPPlan igemm_pp1_plan(const Ctx& ctx, const IGemm& p);
 size_t igemm_pp1_workspace_floats(const IGemm& p, const PPPlan& pl);
-const char* igemm_pp1_name(const PPPlan& pl);
+const char* igemm_pp1_name(const PPPlan& pl, int terms);
 void launch_igemm_pp1(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float* part);
 
 // ------------------------------------------------------------------------------------------ norms etc.

@@ -297,11 +297,11 @@ struct Vocoder::Impl {
             // MRF: x = (rb_0(y) + rb_1(y) + rb_2(y)) / n on the SAME input (hifigan.py:158-164)
             T4 xs = alloc_t(ctx, B, 1, L, u.cout);
             const float inv_n = 1.0f / (float)cfg.n_kernels;
-            // Wide HiFi-GAN stages in the bf16x3 mode: every MRF convolution reads a pre-activated, pre-split input --
+            // Wide HiFi-GAN stages in the bf16 modes: every MRF convolution reads a pre-activated, pre-split input --
             // leaky(x) as split32 lines, written by the producer's epilogue -- so that both operands reach LDS by DMA and
             // the contraction runs on the ping-pong engine (C >= 128: the layer is matrix work, not HBM traffic; the
             // narrow stages keep the halo kernel).
-            const bool presplit = !big && ctx.dtype == 1 && u.cout >= 128 && u.cout % 32 == 0;
+            const bool presplit = !big && ctx.dtype != 0 && u.cout >= 128 && u.cout % 32 == 0;
             T4 ys;
             if (presplit) {
                 ys = alloc_t(ctx, B, 1, L, u.cout);
