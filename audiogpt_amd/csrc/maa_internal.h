@@ -139,6 +139,7 @@ struct Tuning {
     bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
     bool xcd_align = true;                  // MAA_XCD_ALIGN=0: normalisation / attention / reduce workgroups in plain blockIdx order (A/B of xcd_contiguous)
     bool gn_two_pass = false;               // MAA_GN_TWO_PASS=1: GroupNorm as the statistics + apply launches of rounds 1-4 everywhere (A/B, tests)
+    bool attn_split = true;                 // MAA_ATTN_SPLIT=0: the UNet's q / k / v projections write fp32 rows and the attention kernel splits them per tile (rounds 1-4; A/B, tests)
     bool cfg_split = true;                  // MAA_CFG_SPLIT=0: the two halves of a classifier-free-guidance step one after the other on one stream
     void load();
 };
@@ -276,7 +277,10 @@ void launch_split32_unpack(const Ctx& ctx, const float* x, long long rows, int C
 // fused softmax(alpha q k^T) v for the bf16 precision modes; false = shape not covered, use the GEMM path
 bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
                             const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,
-                            float* out, int ldo, int out_split = 0, int causal = 0);
+                            float* out, int ldo, int out_split = 0, int causal = 0, int in_split = 0, int cq = 0, int ck = 0,
+                            int cv = 0);
+// in_split: q / k / v are the ROW bases of split32 rows (c_split outputs of the projections); cq / ck / cv = channel of head 0's
+// first element inside those rows, head h starts hs{q,k,v} channels further (all multiples of 8)
 bool flash_attention_covers(const Ctx& ctx, int dh);    // head widths launch_flash_attention takes in this mode
 // in-place row softmax over `cols` columns of a [rows, ld] matrix; columns [cols, ld) are zeroed
 void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld, int causal_nq = 0);

@@ -108,6 +108,78 @@ def test_attention(ctx, B, heads, dh, Nq, Nk):
           TOL[ctx.precision] * (5 if dh >= 256 else 1))
 
 
+class _env:
+    """MAA_* knobs for one block (the library parses them when a context is created; reload_tuning() re-reads them)."""
+
+    def __init__(self, **env):
+        self.env = env
+
+    def __enter__(self):
+        import os
+        from audiogpt_amd.backend import reload_tuning
+        self.saved = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+        reload_tuning()
+
+    def __exit__(self, *a):
+        import os
+        from audiogpt_amd.backend import reload_tuning
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        reload_tuning()
+
+
+@pytest.mark.parametrize("B,heads,dh,Nq,Nk", [(2, 8, 40, 780, 780), (2, 8, 40, 780, 77), (2, 8, 80, 195, 195), (2, 8, 80, 195, 77),
+                                              (3, 16, 32, 195, 1), (1, 8, 40, 1060, 1060), (2, 4, 64, 130, 33), (1, 8, 80, 265, 265),
+                                              (1, 8, 40, 12, 45)])
+def test_attention_with_split32_inputs(ctx, B, heads, dh, Nq, Nk):
+    """The form the UNet runs since round 5: q / k / v handed to the fused kernel as split32 rows (MAA_OP_PRESPLIT=1 packs them
+    before the launch; in the models the projections' epilogues write them), no hi / lo split inside the kernel, the softmax
+    scale applied to the scores instead of to Q -- against the same fp32 reference and tolerance as the fp32-input form."""
+    Cc = heads * dh
+    q = torch.randn(B, Nq, Cc, generator=g(34))
+    k = torch.randn(B, Nk, Cc, generator=g(35))
+    v = torch.randn(B, Nk, Cc, generator=g(36))
+    alpha = dh ** -0.5
+
+    def split(t):
+        return t.reshape(B, t.shape[1], heads, dh).permute(0, 2, 1, 3)
+    sim = torch.einsum("bhid,bhjd->bhij", split(q), split(k)) * alpha
+    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), split(v)).permute(0, 2, 1, 3).reshape(B, Nq, Cc)
+    with _env(MAA_OP_PRESPLIT="1"):
+        y = ctx.op_attention(q, k, v, heads, alpha)
+        y2 = ctx.op_attention(q, k, v, heads, alpha)
+    assert torch.equal(y.cpu(), y2.cpu())
+    check(f"{ctx.precision}_attention_split_in_h{heads}_d{dh}_{Nq}x{Nk}", y, ref, TOL[ctx.precision])
+    if ctx.precision == "bf16x3":      # the two input forms differ only in where the scale is applied: ~2^-16 apart
+        y_f = ctx.op_attention(q, k, v, heads, alpha)
+        r, _, _ = rel_err(y, y_f.cpu())
+        assert r <= 5e-5, r
+
+
+def test_unet_with_and_without_split32_attention_inputs(golden, ctx3):
+    """MAA_ATTN_SPLIT=0 restores rounds 1-4's arrangement (fp32 q / k / v rows, split per tile inside the attention kernel): the
+    whole T2A UNet must meet the reference golden either way, and the two agree far inside the gate."""
+    from audiogpt_amd.backend import UNet
+    gu = golden("unet_t2a")
+    x, t, c = torch.from_numpy(gu["x"]), torch.from_numpy(gu["t"]), torch.from_numpy(gu["context"])
+    outs = {}
+    for tag, val in (("split", "1"), ("fp32", "0")):
+        with _env(MAA_ATTN_SPLIT=val):
+            unet = UNet(ctx3, C.UNET_T2A, WT.make_unet_state_dict(C.UNET_T2A, seed=0))
+            ctx3.prof_begin()
+            outs[tag] = unet(x, t, c).cpu()
+            rows = ctx3.prof_end()
+            unet.close()
+        assert "flash_attention" in rows
+        check(f"bf16x3_unet_t2a_attn_{tag}", outs[tag], gu["y"], 1e-4)
+    r, _, _ = rel_err(outs["split"], outs["fp32"])
+    assert 0 < r <= 2e-5, r
+
+
 def _tables(S):
     from oracle import ddim as O
     ac = O.alphas_cumprod(1000, C.LDM_T2A["linear_start"], C.LDM_T2A["linear_end"])
