@@ -640,24 +640,8 @@ int maa_op_attention(maa_ctx* ctx, const float* d_q, const float* d_k, const flo
         MAA_CHECK(d_q && d_k && d_v && d_y, "bad op_attention arguments");
         maa::Ctx& c = ctx->c;
         const int C = heads * dh;
-        // MAA_OP_PRESPLIT=1 (tests): q / k / v handed to the fused kernel as split32 rows, the form the UNet's projections write
-        const bool pre = c.tune.op_presplit && c.dtype != 0 && C % 32 == 0 && dh % 8 == 0 && maa::flash_attention_covers(c, dh);
         maa::run_sized(c, [&] {
-            if (!pre) {
-                maa::attention_into(c, d_q, C, dh, d_k, C, dh, d_v, C, dh, B, heads, dh, Nq, Nk, alpha, d_y, C);
-                return;
-            }
-            const size_t mk = c.ws.mark();
-            float* qs = c.ws.alloc_f((size_t)B * Nq * C);
-            float* ks = c.ws.alloc_f((size_t)B * Nk * C);
-            float* vs = c.ws.alloc_f((size_t)B * Nk * C);
-            if (!c.ws.dry) {
-                maa::launch_split32_pack(c, d_q, (long long)B * Nq, C, qs);
-                maa::launch_split32_pack(c, d_k, (long long)B * Nk, C, ks);
-                maa::launch_split32_pack(c, d_v, (long long)B * Nk, C, vs);
-            }
-            maa::attention_into(c, qs, C, dh, ks, C, dh, vs, C, dh, B, heads, dh, Nq, Nk, alpha, d_y, C, 0, 0, 1, 0, 0, 0);
-            c.ws.release(mk);
+            maa::attention_into(c, d_q, C, dh, d_k, C, dh, d_v, C, dh, B, heads, dh, Nq, Nk, alpha, d_y, C);
         });
         MAA_HIP(hipStreamSynchronize(c.stream));
     });

@@ -91,12 +91,12 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
 
 void attention_into(Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk, const float* v,
                     int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha, float* out, int ldo,
-                    int out_split, int causal, int in_split, int cq, int ck, int cv) {
+                    int out_split, int causal) {
     MAA_CHECK(!causal || Nq == Nk, "causal attention needs Nq == Nk");
     if (launch_flash_attention(ctx, q, ldq, hsq, k, ldk, hsk, v, ldv, hsv, B, heads, dh, Nq, Nk, alpha, out, ldo,
-                               out_split, causal, in_split, cq, ck, cv))
+                               out_split, causal))
         return;
-    MAA_CHECK(!out_split && !in_split, "split32 attention inputs / output need the fused kernel");
+    MAA_CHECK(!out_split, "split32 attention output needs the fused kernel");
     const size_t mk = ctx.ws.mark();
     const int ldS = (Nk + 3) / 4 * 4;
     float* S = ctx.ws.alloc_f((size_t)B * heads * Nq * ldS);

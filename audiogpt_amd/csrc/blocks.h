@@ -57,8 +57,7 @@ void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const
 //   out: [B, Nq, heads*dh] dense
 void attention_into(Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk, const float* v,
                     int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha, float* out, int ldo,
-                    int out_split = 0, int causal = 0, int in_split = 0, int cq = 0, int ck = 0, int cv = 0);
-// in_split: q / k / v = row bases of split32 rows, cq / ck / cv the channel of head 0 in them (launch_flash_attention)
+                    int out_split = 0, int causal = 0);
 // causal: query i attends to keys 0 .. i only (Nq == Nk)
 // out_split: write split32 rows (only where flash_attention_covers(ctx, dh))
 

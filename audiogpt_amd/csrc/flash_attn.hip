@@ -37,7 +37,6 @@ struct FlashArgs {
     int out_split;                // write split32 lines (the to_out projection reads them with no conversion)
     int causal;                   // query i sees keys 0 .. i only (OpenCLIP's text tower)
     int qtiles, xcd_on;           // 128-query tiles per (sample, head); XCD-contiguous work order (maa_internal.h)
-    int cq, ck, cv;               // SPLIT_IN: q / k / v are ROW bases of split32 rows; channel of head 0's first element in them
     long long o_bs;
     const float* zeros;
 };
@@ -56,19 +55,13 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     hi = pk_bf16(a, b);
     lo = pk_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
 }
-// bf16 index of channel c's hi half inside a split32 row (32 channels = one 128-byte line [32 hi | 32 lo]); lo half: + 32
-__device__ __forceinline__ int split_off(int c) { return ((c >> 5) << 6) + (c & 31); }
 struct Frag {      // 8 bf16 = 4 dwords, bit-castable to the MFMA operand type
     unsigned w[4];
 };
 __device__ __forceinline__ bf16x8 as_bf16x8(const Frag& f) { return __builtin_bit_cast(bf16x8, f); }
 
 // (capping the d = 40 kernel at 128 VGPRs -- four workgroups per CU -- spills and is 20 % slower: DESIGN.md 3.3)
-// SPLIT_IN: q / k / v arrive as split32 rows (written by the projections' epilogues, c_split): the operands reach the MFMA with no
-// conversion -- no hi/lo split of K and V per tile and workgroup (each of a (sample, head)'s seven query tiles repeated it), V^T
-// built with byte permutes -- and the softmax scale, which cannot ride on a pre-split Q, is the multiplier of the one FMA per
-// score that replaces the subtraction of the running maximum.
-template <int DH, int TERMS, bool SPLIT_IN>
+template <int DH, int TERMS>
 __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
     constexpr int DK = (DH + 15) / 16 * 16;      // head dim padded to the MFMA k-step
     constexpr int DM = (DH + 31) / 32 * 32;      // rows of O^T
@@ -91,11 +84,9 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
     const int bh = w / a.qtiles, b = bh / a.heads, h = bh - b * a.heads;
     const int q0 = (w - bh * a.qtiles) * 128 + wid * 32;
     const bool wave_live = q0 < a.Nq;          // wave-uniform
-    const float* qp = a.q + b * a.q_bs + (SPLIT_IN ? 0 : h * a.hsq);
-    const float* kp = a.k + b * a.k_bs + (SPLIT_IN ? 0 : h * a.hsk);
-    const float* vp = a.v + b * a.v_bs + (SPLIT_IN ? 0 : h * a.hsv);
-    const int cqh = a.cq + h * a.hsq, ckh = a.ck + h * a.hsk, cvh = a.cv + h * a.hsv;      // (SPLIT_IN) first channel of this head
-    const uint4* zero16 = reinterpret_cast<const uint4*>(a.zeros);
+    const float* qp = a.q + b * a.q_bs + h * a.hsq;
+    const float* kp = a.k + b * a.k_bs + h * a.hsk;
+    const float* vp = a.v + b * a.v_bs + h * a.hsv;
     const float4* zero4 = reinterpret_cast<const float4*>(a.zeros);
 
     // ---- zero both LDS buffers once: the padding (d >= DH rows / columns, keys of a short last tile) must be 0
@@ -112,18 +103,6 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int d = ks * 16 + lh * 8;
-            if constexpr (SPLIT_IN) {
-                // 8 channels from a multiple of 8: inside one split32 line
-                const unsigned short* s16 = reinterpret_cast<const unsigned short*>(src) + split_off(cqh + d);
-                const bool ok = qok && d < DH;
-                const uint4 hv = *(ok ? reinterpret_cast<const uint4*>(s16) : zero16);
-                qh[ks].w[0] = hv.x, qh[ks].w[1] = hv.y, qh[ks].w[2] = hv.z, qh[ks].w[3] = hv.w;
-                if constexpr (TERMS == 3) {
-                    const uint4 lv = *(ok ? reinterpret_cast<const uint4*>(s16 + 32) : zero16);
-                    ql[ks].w[0] = lv.x, ql[ks].w[1] = lv.y, ql[ks].w[2] = lv.z, ql[ks].w[3] = lv.w;
-                }
-                continue;
-            }
             float4 x0 = *((qok && d < DH) ? reinterpret_cast<const float4*>(src + d) : zero4);
             float4 x1 = *((qok && d + 4 < DH) ? reinterpret_cast<const float4*>(src + d + 4) : zero4);
             x0.x *= qs;
@@ -156,44 +135,12 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
     // blocks are dealt from the last thread down and the second pass of K from the first thread up, so no thread gets both
     // extras (d = 40: threads 0-63 two K elements, 96-255 one K element + one V block).
     constexpr int C2 = DH / 2;
-    constexpr int NK = SPLIT_IN ? KT * (DH / 8) : KT * C4, NV = SPLIT_IN ? (KT / 4) * C4 : (KT / 4) * C2;
+    constexpr int NK = KT * C4, NV = (KT / 4) * C2;
     constexpr int NLK = (NK + NT - 1) / NT, NLV = (NV + NT - 1) / NT;
-    float4 rk[SPLIT_IN ? 1 : NLK];
-    float2 rv[SPLIT_IN ? 1 : NLV][4];
-    // SPLIT_IN.  K: idx -> (key, 8 d): one 16-byte load and one 16-byte LDS store per plane.  V: idx -> (4 keys kb, 4 d c4): an
-    // 8-byte load per key and plane; V^T[d][4 keys] = two byte permutes per d and plane, one 8-byte store.
-    constexpr int C8 = DH / 8;
-    uint4 skh[SPLIT_IN ? NLK : 1], skl[SPLIT_IN && TERMS == 3 ? NLK : 1];
-    uint2 svh[SPLIT_IN ? NLV : 1][4], svl[SPLIT_IN && TERMS == 3 ? NLV : 1][4];
+    float4 rk[NLK];
+    float2 rv[NLV][4];
     const float2* zero2 = reinterpret_cast<const float2*>(a.zeros);
-    const uint2* zero8 = reinterpret_cast<const uint2*>(a.zeros);
     auto load_tile = [&](int kt) {
-        if constexpr (SPLIT_IN) {
-#pragma unroll
-            for (int j = 0; j < NLK; ++j) {
-                const int idx = tid + NT * j;
-                const int key = idx / C8, c8 = idx - key * C8;
-                const int kg = kt * KT + key;
-                const bool ok = idx < NK && kg < a.Nk;
-                const unsigned short* s16 = reinterpret_cast<const unsigned short*>(kp + (long long)(ok ? kg : 0) * a.ldk) + split_off(ckh + c8 * 8);
-                skh[j] = *(ok ? reinterpret_cast<const uint4*>(s16) : zero16);
-                if constexpr (TERMS == 3) skl[j] = *(ok ? reinterpret_cast<const uint4*>(s16 + 32) : zero16);
-            }
-#pragma unroll
-            for (int j = 0; j < NLV; ++j) {
-                const int idx = (NT - 1 - tid) + NT * j;
-                const int kb = idx / C4, c4 = idx - kb * C4;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int kg = kt * KT + kb * 4 + k;
-                    const bool ok = idx < NV && kg < a.Nk;
-                    const unsigned short* s16 = reinterpret_cast<const unsigned short*>(vp + (long long)(ok ? kg : 0) * a.ldv) + split_off(cvh + c4 * 4);
-                    svh[j][k] = *(ok ? reinterpret_cast<const uint2*>(s16) : zero8);
-                    if constexpr (TERMS == 3) svl[j][k] = *(ok ? reinterpret_cast<const uint2*>(s16 + 32) : zero8);
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int j = 0; j < NLK; ++j) {
             const int idx = tid + NT * j;
@@ -217,44 +164,6 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
     auto store_tile = [&](int buf) {
         unsigned short* base = smem + buf * BUF;
         unsigned short* vt = base + PL * K_PLANE;
-        if constexpr (SPLIT_IN) {
-#pragma unroll
-            for (int j = 0; j < NLK; ++j) {
-                const int idx = tid + NT * j;
-                if (idx < NK) {
-                    const int key = idx / C8, c8 = idx - key * C8;
-                    *reinterpret_cast<uint4*>(base + key * LDKK + c8 * 8) = skh[j];
-                    if constexpr (TERMS == 3) *reinterpret_cast<uint4*>(base + K_PLANE + key * LDKK + c8 * 8) = skl[j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NLV; ++j) {
-                const int idx = (NT - 1 - tid) + NT * j;
-                if (idx < NV) {
-                    const int kb = idx / C4, c4 = idx - kb * C4;
-                    // w[k] = (d, d + 1) of key k as one word; V^T[d][keys 0..3] = the low halves of w[0..3], V^T[d + 1] the high halves
-                    auto put4 = [&](unsigned short* plane, const uint2 (&w)[4]) {
-                        unsigned short* o = plane + (4 * c4) * LDV + kb * 4;
-                        uint2 t;
-                        t.x = __builtin_amdgcn_perm(w[1].x, w[0].x, 0x05040100u);
-                        t.y = __builtin_amdgcn_perm(w[3].x, w[2].x, 0x05040100u);
-                        *reinterpret_cast<uint2*>(o) = t;
-                        t.x = __builtin_amdgcn_perm(w[1].x, w[0].x, 0x07060302u);
-                        t.y = __builtin_amdgcn_perm(w[3].x, w[2].x, 0x07060302u);
-                        *reinterpret_cast<uint2*>(o + LDV) = t;
-                        t.x = __builtin_amdgcn_perm(w[1].y, w[0].y, 0x05040100u);
-                        t.y = __builtin_amdgcn_perm(w[3].y, w[2].y, 0x05040100u);
-                        *reinterpret_cast<uint2*>(o + 2 * LDV) = t;
-                        t.x = __builtin_amdgcn_perm(w[1].y, w[0].y, 0x07060302u);
-                        t.y = __builtin_amdgcn_perm(w[3].y, w[2].y, 0x07060302u);
-                        *reinterpret_cast<uint2*>(o + 3 * LDV) = t;
-                    };
-                    put4(vt, svh[j]);
-                    if constexpr (TERMS == 3) put4(vt + V_PLANE, svl[j]);
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int j = 0; j < NLK; ++j) {
             const int idx = tid + NT * j;
@@ -356,23 +265,11 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
             // after the first tiles, so the rescale of O is skipped for a wave whose lanes all kept their maximum (alpha == 1
             // exactly)
             float alpha, ls = 0.f;
-            if constexpr (SPLIT_IN) {
-                // raw scores: scale * log2 e is the multiplier of the FMA that takes the maximum off (m_run / m_new in raw units)
-                const float qs = a.scale * 1.4426950408889634f;
-                const float mq = -m_new * qs;
-                alpha = __builtin_amdgcn_exp2f((m_run - m_new) * qs);       // first tile: exp2(-inf) = 0
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);                  // first tile: exp2(-inf) = 0
     #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[r], qs, mq));      // masked keys: exp2(-inf) = 0
-                    ls += p[r];
-                }
-            } else {
-                alpha = __builtin_amdgcn_exp2f(m_run - m_new);              // first tile: exp2(-inf) = 0
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    p[r] = __builtin_amdgcn_exp2f(p[r] - m_new);            // masked keys: exp2(-inf) = 0
-                    ls += p[r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(p[r] - m_new);                // masked keys: exp2(-inf) = 0
+                ls += p[r];
             }
             ls += __shfl_xor(ls, 32, 64);
             l_run = l_run * alpha + ls;
@@ -460,24 +357,16 @@ __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
     }
 }
 
-template <int DH, int TERMS, bool SPLIT_IN>
-void launch_dh_in(const Ctx& ctx, const FlashArgs& a, int B) {
+template <int DH, int TERMS>
+void launch_dh(const Ctx& ctx, const FlashArgs& a, int B) {
     constexpr int DK = (DH + 15) / 16 * 16, DM = (DH + 31) / 32 * 32, PL = TERMS == 1 ? 1 : 2;
     constexpr size_t kv = (size_t)2 * PL * (KT * (DK + 8) + DM * (KT + 4)) * sizeof(unsigned short);
     constexpr size_t tr = (size_t)4 * 32 * (DM + 1) * sizeof(float);
     constexpr size_t lds = kv > tr ? kv : tr;
-    auto kern = flash_attn_kernel<DH, TERMS, SPLIT_IN>;
+    auto kern = flash_attn_kernel<DH, TERMS>;
     ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
     dim3 grid((unsigned)(a.qtiles * B * a.heads));
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx.stream, a);
-}
-
-template <int DH, int TERMS>
-void launch_dh(const Ctx& ctx, const FlashArgs& a, int B, bool in_split) {
-    if (in_split)
-        launch_dh_in<DH, TERMS, true>(ctx, a, B);
-    else
-        launch_dh_in<DH, TERMS, false>(ctx, a, B);
 }
 
 }  // namespace
@@ -489,21 +378,10 @@ bool flash_attention_covers(const Ctx& ctx, int dh) {
 // false: shape not covered (head dim other than 32 / 40 / 64 / 80, unaligned rows) -> caller uses the GEMM path
 bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
                             const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,
-                            float* out, int ldo, int out_split, int causal, int in_split, int cq, int ck, int cv) {
-    if (!flash_attention_covers(ctx, dh)) {
-        MAA_CHECK(!in_split, "split32 attention inputs need the fused kernel");
-        return false;
-    }
+                            float* out, int ldo, int out_split, int causal) {
+    if (!flash_attention_covers(ctx, dh)) return false;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    if (in_split) {
-        // q / k / v = row bases of split32 rows (whole 128-byte lines), a head's first channel a multiple of 8
-        auto al128 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 127) == 0; };
-        MAA_CHECK(ldq % 32 == 0 && ldk % 32 == 0 && ldv % 32 == 0 && al128(q) && al128(k) && al128(v) &&
-                  (hsq | hsk | hsv | cq | ck | cv) % 8 == 0 && cq >= 0 && ck >= 0 && cv >= 0,
-                  "split32 attention inputs: row / head alignment");
-    } else if (ldq % 4 || ldk % 4 || ldv % 4 || hsq % 4 || hsk % 4 || hsv % 4 || !al16(q) || !al16(k) || !al16(v)) {
-        return false;
-    }
+    if (ldq % 4 || ldk % 4 || ldv % 4 || hsq % 4 || hsk % 4 || hsv % 4 || !al16(q) || !al16(k) || !al16(v)) return false;
     if (ctx.ws.dry) return true;
     FlashArgs a;
     a.q = q;
@@ -530,18 +408,15 @@ bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, co
     a.zeros = ctx.zeros;
     a.qtiles = (Nq + 127) / 128;
     a.xcd_on = ctx.tune.xcd_align ? 1 : 0;
-    a.cq = cq;
-    a.ck = ck;
-    a.cv = cv;
     const double flops = 4.0 * B * heads * (double)Nq * Nk * dh;
     const double bytes = 4.0 * B * heads * ((double)2 * Nq * dh + 2.0 * Nk * dh);
     ProfScope prof(ctx, "flash_attention", flops, bytes);
     const int terms = ctx.dtype == 1 ? 3 : 1;
 #define MAA_FLASH(DHV)                                 \
     if (terms == 3)                                    \
-        launch_dh<DHV, 3>(ctx, a, B, in_split != 0);   \
+        launch_dh<DHV, 3>(ctx, a, B);                  \
     else                                               \
-        launch_dh<DHV, 1>(ctx, a, B, in_split != 0);
+        launch_dh<DHV, 1>(ctx, a, B);
     switch (dh) {
         case 32: MAA_FLASH(32) break;
         case 40: MAA_FLASH(40) break;

@@ -233,6 +233,259 @@ __global__ __launch_bounds__(256) void halo_conv1d_kernel(const HaloArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- fused MRF pair
+// One launch for the pair of an MRF resblock at the narrow stages (hifigan.py:54-61):
+//     xt = c1(leaky(x));  xt = c2(leaky(xt));  x' = xt + x          (c1: k taps, dilation d1;  c2: k taps, dilation d2 = 1)
+// The intermediate tensor never leaves the CU: 20 B of HBM traffic per element and pair (x in, t out, t in, x as residual, x' out)
+// become 8 + the residual's re-read out of L2, and there is one staging pass and one launch instead of two.
+//
+// A tile is R1 = 128 MI rows of t -- positions l0 - H2 .. l0 - H2 + R1 - 1, H2 = d2 (k2 - 1) / 2 -- computed exactly as the
+// one-convolution kernel computes them out of the staged image of leaky(x) (rows l0 - H2 - H1 ..).  The accumulators then
+// take the first epilogue in registers (+ bias1, rows outside the sample -> 0: c2's zero padding), leaky-ReLU, hi / lo split,
+// and are written over the x image as the split32 image of leaky(t) (the accumulator layout holds one column per lane: lane
+// pairs swap halves so that every lane writes whole 4-byte words).  The second convolution reads it like the first read x;
+// of its R1 output rows the first TLo = R1 - 2 H2 are positions l0 .. l0 + TLo - 1 and are stored through the shared
+// epilogue (bias2, residual x, out_scale, accumulate); the last 2 H2 rows multiply rows past the image and are dropped.
+// The weights of both convolutions stream through ONE ring as a single sequence of chunks.
+// Arithmetic = the two launches': same products, same order, same fp32 epilogue in between -- bit-identical (tests).
+struct HaloPairArgs {
+    IGemm g;             // second convolution: b / ldb / bias, res, ldr, out_scale, accumulate, c, ldc, N, zeros
+    const float* x;      // [B, L, C] fp32
+    const float* w1;     // first convolution: packed split32 weights [C][k1 C], pitch ldb1 floats
+    const float* bias1;
+    int ldb1;
+    int B, L, k1, d1, k2, d2;
+    float slope1, slope2;
+    int TLo, tiles_per_sample, tiles;
+};
+
+constexpr int HMAX2 = 16;          // rows the second convolution may reach past the t image (d2 (k2 - 1) <= HMAX2)
+
+template <int C, int TL, int NSB>
+__global__ __launch_bounds__(256) void halo_pair_kernel(const HaloPairArgs a) {
+    constexpr int AROWS = TL + 2 * HMAX;       // x image (the t image, TL + HMAX2 rows, is written over it)
+    constexpr int CB = C / 32;
+    constexpr int NI = C / 32, MI = TL / 128;
+    static_assert(TL == 128 || TL == 256, "tile length");
+    static_assert(TL + HMAX2 <= AROWS, "t image inside the x image");
+    constexpr int A_BYTES = AROWS * CB * 128;
+    constexpr int BSTAGE = C * 128;
+    constexpr int IPW = C / 32;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [AROWS][CB][128] | [NSB][C][128]
+    char* bring = smem + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lk = lane >> 5;
+    const int H1 = a.d1 * (a.k1 - 1) / 2, H2 = a.d2 * (a.k2 - 1) / 2;
+    const int n1 = a.k1 * CB, nchunks = n1 + a.k2 * CB;
+
+    const int r8 = lane >> 3;
+    const int bslot = (((lane & 7) ^ (((wid & 1) << 2) + (r8 >> 1))) << 4);
+    const char *wrow1[IPW], *wrow2[IPW];
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) {
+        wrow1[j] = reinterpret_cast<const char*>(a.w1) + (long long)(8 * (j * 4 + wid) + r8) * a.ldb1 * 4 + bslot;
+        wrow2[j] = reinterpret_cast<const char*>(a.g.b) + (long long)(8 * (j * 4 + wid) + r8) * a.g.ldb * 4 + bslot;
+    }
+    auto issue_b = [&](int stage, int chunk) __attribute__((always_inline)) {
+        const bool live = chunk < nchunks, first = chunk < n1;
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            const char* src = !live ? reinterpret_cast<const char*>(a.g.zeros)
+                                    : first ? wrow1[j] + (long long)chunk * 128 : wrow2[j] + (long long)(chunk - n1) * 128;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(bring + stage * BSTAGE + (j * 4 + wid) * 1024), 16, 0, 0);
+        }
+    };
+    const int bswz = (lrow >> 1) & 7;
+    int b_off[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) b_off[pl][ks] = lrow * 128 + (((pl * 4 + ks * 2 + lk) ^ bswz) << 4);
+
+    for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+        const int b = tile / a.tiles_per_sample;
+        const int l0 = (tile - b * a.tiles_per_sample) * a.TLo;
+        const int t0 = l0 - H2;                    // position of row 0 of the t image
+#pragma unroll
+        for (int s = 0; s < NSB - 1; ++s) issue_b(s, s);
+        // ---- x image: rows r <-> positions t0 - H1 + r, r < TL + 2 H1 (as the one-convolution kernel)
+        {
+            const int rows = TL + 2 * H1;
+            constexpr int PPR = C / 8;
+            constexpr int NPT = (AROWS * PPR + 255) / 256;
+            const float* xb = a.x + (long long)b * a.L * C;
+            float4 v0[NPT], v1[NPT];
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const int p0 = tid + 256 * u;
+                const int r = p0 / PPR, q = p0 - r * PPR;
+                int l = t0 - H1 + r;
+                l = l < 0 ? 0 : (l >= a.L ? a.L - 1 : l);
+                const float4* src = reinterpret_cast<const float4*>(xb + (long long)l * C + q * 8);
+                v0[u] = src[0];
+                v1[u] = src[1];
+            }
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const int p0 = tid + 256 * u;
+                const int r = p0 / PPR, q = p0 - r * PPR;
+                const int l = t0 - H1 + r;
+                if (r < rows) {
+                    const float s = (l >= 0 && l < a.L) ? a.slope1 : 0.f;
+                    const float m = (l >= 0 && l < a.L) ? 1.f : 0.f;
+                    float4 w0 = v0[u], w1 = v1[u];
+                    w0.x = fmaxf(w0.x * m, w0.x * s);
+                    w0.y = fmaxf(w0.y * m, w0.y * s);
+                    w0.z = fmaxf(w0.z * m, w0.z * s);
+                    w0.w = fmaxf(w0.w * m, w0.w * s);
+                    w1.x = fmaxf(w1.x * m, w1.x * s);
+                    w1.y = fmaxf(w1.y * m, w1.y * s);
+                    w1.z = fmaxf(w1.z * m, w1.z * s);
+                    w1.w = fmaxf(w1.w * m, w1.w * s);
+                    unsigned h0, h1, h2, h3, q0, q1, q2, q3;
+                    split2(w0.x, w0.y, h0, q0);
+                    split2(w0.z, w0.w, h1, q1);
+                    split2(w1.x, w1.y, h2, q2);
+                    split2(w1.z, w1.w, h3, q3);
+                    const u32x4 hi = {h0, h1, h2, h3}, lo = {q0, q1, q2, q3};
+                    const int cb = q >> 2, sl = q & 3, sw = (r >> 1) & 7;
+                    char* line = smem + (r * CB + cb) * 128;
+                    *reinterpret_cast<u32x4*>(line + ((sl ^ sw) << 4)) = hi;
+                    *reinterpret_cast<u32x4*>(line + (((4 + sl) ^ sw) << 4)) = lo;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        f32x16 acc[MI][NI];
+        auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        };
+        zero_acc();
+
+        int st = 0, st_fill = NSB - 1;
+        int tap = 0, cb = 0, dil = a.d1;
+        for (int c = 0; c < nchunks; ++c) {
+            if (c == n1) {
+                // ---- between the convolutions: t = acc + bias1 (the first launch's epilogue), rows outside the sample are c2's
+                // zero padding, leaky-ReLU and split exactly as the second launch's staging did, written over the x image
+                __builtin_amdgcn_s_barrier();      // every wave has read its last x rows
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const int n = j * 32 + lrow;
+                        const float bv = a.bias1 ? a.bias1[n] : 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = wid * (32 * MI) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                            const int l = t0 + row;
+                            const bool in = l >= 0 && l < a.L;
+                            float v = acc[i][j][r] * 1.0f + bv;
+                            v = in ? fmaxf(v * 1.f, v * a.slope2) : 0.f;
+                            const __bf16 hb16 = (__bf16)v;
+                            const unsigned hb = __builtin_bit_cast(unsigned short, hb16);
+                            const __bf16 lb16 = (__bf16)(v - __builtin_bit_cast(float, hb << 16));
+                            const unsigned lb = __builtin_bit_cast(unsigned short, lb16);
+                            // lanes 2m / 2m + 1 hold columns n / n + 1 of the same row: the even lane writes both hi halves, the odd
+                            // lane both lo halves (one 4-byte LDS store per lane and element)
+                            const bool even = (lane & 1) == 0;
+                            const unsigned mine = even ? lb : hb;
+                            const unsigned theirs = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, false);
+                            const unsigned word = even ? (hb | (theirs << 16)) : (theirs | (lb << 16));
+                            // channel pair (n & ~1) of line j: 16-byte slot ((n & 31) >> 3) (+ 4 for the lo half), swizzled by the row
+                            const int sl = ((n & 31) >> 3) + (even ? 0 : 4), sw = (row >> 1) & 7;
+                            char* line = smem + (row * CB + j) * 128;
+                            *reinterpret_cast<unsigned*>(line + ((sl ^ sw) << 4) + ((n & 6) << 1)) = word;
+                        }
+                    }
+                // rows TL .. TL + 2 H2 - 1 of the t image feed only output rows that are dropped, but must be finite
+                for (int e = tid; e < 2 * H2 * CB * 8; e += 256)
+                    reinterpret_cast<u32x4*>(smem + TL * CB * 128)[e] = u32x4{0u, 0u, 0u, 0u};
+                zero_acc();
+                tap = 0;
+                cb = 0;
+                dil = a.d2;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            wait_vmcnt<(NSB - 2) * IPW>();
+            __builtin_amdgcn_s_barrier();          // chunk c of the weights is in LDS (and, at c = 0 / n1, the whole image)
+            issue_b(st_fill, c + NSB - 1);
+            const char* bst = bring + st * BSTAGE;
+            bf16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wid * (32 * MI) + i * 32 + lrow + tap * dil;
+                const char* line = smem + (row * CB + cb) * 128;
+                const int sw = (row >> 1) & 7;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    ah[ks][i] = *reinterpret_cast<const bf16x8*>(line + (((ks * 2 + lk) ^ sw) << 4));
+                    al[ks][i] = *reinterpret_cast<const bf16x8*>(line + (((4 + ks * 2 + lk) ^ sw) << 4));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bh[ks][j] = *reinterpret_cast<const bf16x8*>(bst + j * 4096 + b_off[0][ks]);
+                    bl[ks][j] = *reinterpret_cast<const bf16x8*>(bst + j * 4096 + b_off[1][ks]);
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+            }
+            st = st + 1 == NSB ? 0 : st + 1;
+            st_fill = st_fill + 1 == NSB ? 0 : st_fill + 1;
+            if (++cb == CB) {
+                cb = 0;
+                ++tap;
+            }
+        }
+        wait_vmcnt<0>();
+        // ---- second epilogue: output rows 0 .. TLo - 1 <-> positions l0 ..; rows of the next tile / past the sample are masked by M
+        IGemm q = a.g;
+        const int mrow0 = b * a.L + l0;
+        q.M = b * a.L + min(a.L, l0 + a.TLo);
+        igemm_epilogue<MI, NI>(q, acc, mrow0 + wid * (32 * MI), 0, lrow, lk, 0, C, 1);
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+template <int C, int TL, int NSB>
+void launch_pair_c(const Ctx& ctx, const HaloPairArgs& a) {
+    constexpr size_t lds = (size_t)(TL + 2 * HMAX) * (C / 32) * 128 + (size_t)NSB * C * 128;
+    static_assert(lds <= 163840, "LDS per workgroup");
+    auto kern = halo_pair_kernel<C, TL, NSB>;
+    ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, (int)lds);
+    const int nc = device_cu_count(ctx.device);
+    const int per_cu = (int)(163840 / lds) < 3 ? (int)(163840 / lds) : 3;
+    long long grid = (long long)nc * (per_cu < 1 ? 1 : per_cu);
+    if (grid > a.tiles) grid = a.tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx.stream, a);
+}
+
 template <int C, int TL, int NSB>
 void launch_c(const Ctx& ctx, const HaloArgs& a) {
     constexpr size_t lds = (size_t)(TL + 2 * HMAX) * (C / 32) * 128 + (size_t)NSB * C * 128;
@@ -291,6 +544,59 @@ bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, con
         launch_c<32, 256, 4>(ctx, a);
     else
         launch_c<64, 128, 4>(ctx, a);
+    MAA_HIP(hipGetLastError());
+    return true;
+}
+
+// The MRF pair x' = (c2(leaky(c1(leaky(x)))) + res) * out_scale (+ out) in one launch; conditions as launch_halo_conv1d for both
+// convolutions (same C, odd kernels, "same" padding), d2 (k2 - 1) <= HMAX2.  false: not covered -- the caller launches the two
+// convolutions.  MAA_NO_PAIR=1 disables it (A/B, bit-identity tests).
+bool launch_halo_pair(const Ctx& ctx, const float* x, int B, int L, int C, const PackedW& w1, int k1, int d1, float slope1,
+                      const PackedW& w2, int k2, int d2, float slope2, const float* res, float out_scale, int accumulate,
+                      float* out) {
+    if (ctx.tune.no_halo || ctx.tune.no_pair || ctx.dtype != 1 || !(C == 32 || C == 64)) return false;
+    for (const PackedW* w : {&w1, &w2})
+        if (w->N != C || !w->split || !w->nk) return false;
+    if (w1.K != k1 * C || w2.K != k2 * C) return false;
+    if (k1 < 1 || (k1 & 1) == 0 || d1 < 1 || d1 * (k1 - 1) / 2 > HMAX) return false;
+    if (k2 < 1 || (k2 & 1) == 0 || d2 < 1 || d2 * (k2 - 1) > HMAX2) return false;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0 || (long long)B * L * C >= (1ll << 31)) return false;
+    if (ctx.ws.dry) return true;
+    HaloPairArgs a;
+    a.g.b = w2.w;
+    a.g.ldb = w2.ld;
+    a.g.bias = w2.bias;
+    a.g.res = res;
+    a.g.ldr = C;
+    a.g.out_scale = out_scale;
+    a.g.accumulate = accumulate;
+    a.g.c = out;
+    a.g.ldc = C;
+    a.g.N = C;
+    a.g.M = B * L;
+    a.g.zeros = ctx.zeros;
+    a.x = x;
+    a.w1 = w1.w;
+    a.bias1 = w1.bias;
+    a.ldb1 = w1.ld;
+    a.B = B;
+    a.L = L;
+    a.k1 = k1;
+    a.d1 = d1;
+    a.k2 = k2;
+    a.d2 = d2;
+    a.slope1 = slope1;
+    a.slope2 = slope2;
+    const int TLr = C == 32 ? 256 : 128;
+    a.TLo = TLr - d2 * (k2 - 1);
+    a.tiles_per_sample = (L + a.TLo - 1) / a.TLo;
+    a.tiles = B * a.tiles_per_sample;
+    const double flops = 2.0 * B * (double)L * C * (double)C * (k1 + k2);
+    ProfScope prof(ctx, C == 32 ? "halo_pair_bf16x3<32>" : "halo_pair_bf16x3<64>", flops, 12.0 * B * (double)L * C);
+    if (C == 32)
+        launch_pair_c<32, 256, 4>(ctx, a);
+    else
+        launch_pair_c<64, 128, 4>(ctx, a);
     MAA_HIP(hipGetLastError());
     return true;
 }

@@ -135,11 +135,11 @@ struct Tuning {
     bool op_presplit = false;               // MAA_OP_PRESPLIT=1: the maa_op_* test entry points hand activations over as split32
     int dma_ns_low = 3;                     // MAA_DMA_NS_LOW: LDS stages of a 64x64 LDS-DMA launch with < 2.5 workgroups per CU (2: as the others)
     bool no_dma = false;                    // MAA_NO_DMA: every bf16 contraction on the register-staged engine (bit-identity tests)
+    bool no_pair = false;                   // MAA_NO_PAIR: the MRF pairs of the narrow vocoder stages as two launches (rounds 2-4; A/B, bit-identity test)
     bool no_halo = false;                   // MAA_NO_HALO: the narrow vocoder stages through the implicit GEMM (bit-identity test)
     bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
     bool xcd_align = true;                  // MAA_XCD_ALIGN=0: normalisation / attention / reduce workgroups in plain blockIdx order (A/B of xcd_contiguous)
     bool gn_two_pass = false;               // MAA_GN_TWO_PASS=1: GroupNorm as the statistics + apply launches of rounds 1-4 everywhere (A/B, tests)
-    bool attn_split = true;                 // MAA_ATTN_SPLIT=0: the UNet's q / k / v projections write fp32 rows and the attention kernel splits them per tile (rounds 1-4; A/B, tests)
     bool cfg_split = true;                  // MAA_CFG_SPLIT=0: the two halves of a classifier-free-guidance step one after the other on one stream
     void load();
 };
@@ -277,10 +277,7 @@ void launch_split32_unpack(const Ctx& ctx, const float* x, long long rows, int C
 // fused softmax(alpha q k^T) v for the bf16 precision modes; false = shape not covered, use the GEMM path
 bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, const float* k, int ldk, int hsk,
                             const float* v, int ldv, int hsv, int B, int heads, int dh, int Nq, int Nk, float alpha,
-                            float* out, int ldo, int out_split = 0, int causal = 0, int in_split = 0, int cq = 0, int ck = 0,
-                            int cv = 0);
-// in_split: q / k / v are the ROW bases of split32 rows (c_split outputs of the projections); cq / ck / cv = channel of head 0's
-// first element inside those rows, head h starts hs{q,k,v} channels further (all multiples of 8)
+                            float* out, int ldo, int out_split = 0, int causal = 0);
 bool flash_attention_covers(const Ctx& ctx, int dh);    // head widths launch_flash_attention takes in this mode
 // in-place row softmax over `cols` columns of a [rows, ld] matrix; columns [cols, ld) are zeroed
 void launch_softmax(const Ctx& ctx, float* s, long long rows, int cols, int ld, int causal_nq = 0);
@@ -355,6 +352,10 @@ struct PackedW {
 // staged once in LDS and every tap reads it at a row offset (halo_conv1d.hip).  false: not covered, use the implicit GEMM.
 bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, const PackedW& w, int k, int dil, float slope,
                         const float* res, float out_scale, int accumulate, float* out);
+// the pair c2(leaky(c1(leaky(x)))) + res of an MRF resblock in one launch, the intermediate tensor kept in LDS (halo_conv1d.hip)
+bool launch_halo_pair(const Ctx& ctx, const float* x, int B, int L, int C, const PackedW& w1, int k1, int d1, float slope1,
+                      const PackedW& w2, int k2, int d2, float slope2, const float* res, float out_scale, int accumulate,
+                      float* out);
 
 class WeightStore {
 public:

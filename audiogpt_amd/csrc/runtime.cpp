@@ -176,7 +176,7 @@ void Tuning::load() {
     snake_untiled = !get_s("MAA_SNAKE_UNTILED").empty();
     gn_two_pass = get_s("MAA_GN_TWO_PASS") == "1";
     xcd_align = get_s("MAA_XCD_ALIGN") != "0";
-    attn_split = get_s("MAA_ATTN_SPLIT") != "0";
+    no_pair = get_s("MAA_NO_PAIR") == "1";
     const std::string cs = get_s("MAA_CFG_SPLIT");
     cfg_split = cs.empty() || cs[0] != '0';
     // a stale override in an older round's format ("2,2,0,1": tile, stages ...) is refused here, when the context is created

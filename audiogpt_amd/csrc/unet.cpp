@@ -79,12 +79,6 @@ struct UNet::Impl {
     std::vector<float*> kv_cache;
     std::vector<int> kv_inner;
     int kv_rows = 0, kv_len = 0, kv_batch = 0;
-    bool kv_split_on = false;      // the caches hold split32 rows (decided by set_context: the tuning may be re-read between calls)
-    // q / k / v of a transformer's attentions as split32 rows (flash_attn.hip SPLIT_IN): the bf16 modes, head widths the fused
-    // kernel takes, whole 32-channel lines
-    static bool attn_split_ok(const Ctx& ctx, int heads, int dh) {
-        return split_for_gemm(ctx, heads * dh) && flash_attention_covers(ctx, dh) && dh % 8 == 0;
-    }
     size_t kv_cap_rows = 0;
     DevSlab cfg_context;      // [uncond ; cond] rows of a CFG sample() call
 
@@ -339,10 +333,6 @@ struct UNet::Impl {
         const bool no_osplit = false;
         const int o_sp = !no_osplit && sp && flash_attention_covers(ctx, s.dh) ? 1 : 0;
         const int g_sp = !no_osplit && split_for_gemm(ctx, 4 * inner) ? 1 : 0;
-        // ... and q / k / v feed only the attention kernel: written as split32 rows as well (the cross-attention K / V of the
-        // context by set_context, under the same condition)
-        const int i_sp = ctx.tune.attn_split && attn_split_ok(ctx, s.heads, s.dh) ? 1 : 0;
-        const int x_sp = kv_split_on && attn_split_ok(ctx, s.heads, s.dh) ? 1 : 0;
         int y_sp = 0;
         for (const STBlockW& b : s.blocks) {
             float* ln = ctx.ws.alloc_f((size_t)M * inner);
@@ -350,28 +340,20 @@ struct UNet::Impl {
             // x = attn1(norm1(x)) + x      (attention.py:212)
             launch_layernorm(ctx, y, M, inner, b.ln1g, b.ln1b, 1e-5f, ln, sp);
             float* qkv = ctx.ws.alloc_f((size_t)M * 3 * inner);
-            linear_into(ctx, ln, inner, M, inner, b.qkv1, nullptr, 0, qkv, 3 * inner, 0, 0, sp ? M : 0, i_sp);
-            if (i_sp)      // q | k | v as split32 rows: the attention kernel's operands with no conversion
-                attention_into(ctx, qkv, 3 * inner, s.dh, qkv, 3 * inner, s.dh, qkv, 3 * inner, s.dh, B, s.heads, s.dh, HW, HW,
-                               scale, o, inner, o_sp, 0, 1, 0, inner, 2 * inner);
-            else
-                attention_into(ctx, qkv, 3 * inner, s.dh, qkv + inner, 3 * inner, s.dh, qkv + 2 * inner, 3 * inner, s.dh,
-                               B, s.heads, s.dh, HW, HW, scale, o, inner, o_sp);
+            linear_into(ctx, ln, inner, M, inner, b.qkv1, nullptr, 0, qkv, 3 * inner, 0, 0, sp ? M : 0);
+            attention_into(ctx, qkv, 3 * inner, s.dh, qkv + inner, 3 * inner, s.dh, qkv + 2 * inner, 3 * inner, s.dh,
+                           B, s.heads, s.dh, HW, HW, scale, o, inner, o_sp);
             float* y1 = ctx.ws.alloc_f((size_t)M * inner);
             linear_into(ctx, o, inner, M, inner, b.out1, y, inner, y1, inner, 0, 0, o_sp ? M : 0);
             // x = attn2(norm2(x), context) + x      (:213)
             launch_layernorm(ctx, y1, M, inner, b.ln2g, b.ln2b, 1e-5f, ln, sp);
             float* q = ctx.ws.alloc_f((size_t)M * inner);
-            linear_into(ctx, ln, inner, M, inner, b.q2, nullptr, 0, q, inner, 0, 0, sp ? M : 0, x_sp);
+            linear_into(ctx, ln, inner, M, inner, b.q2, nullptr, 0, q, inner, 0, 0, sp ? M : 0);
             MAA_CHECK(ctx.ws.dry || (kv_cache[b.kv_slot] && (lane ? batch_off + B <= kv_batch : kv_batch == B)),
                       "set_context must precede forward (batch)");
             const float* kv = kv_cache[b.kv_slot] + (size_t)batch_off * kv_len * 2 * inner;
-            if (x_sp)
-                attention_into(ctx, q, inner, s.dh, kv, 2 * inner, s.dh, kv, 2 * inner, s.dh, B, s.heads, s.dh, HW, kv_len, scale,
-                               o, inner, o_sp, 0, 1, 0, 0, inner);
-            else
-                attention_into(ctx, q, inner, s.dh, kv, 2 * inner, s.dh, kv + inner, 2 * inner, s.dh, B, s.heads, s.dh, HW,
-                               kv_len, scale, o, inner, o_sp);
+            attention_into(ctx, q, inner, s.dh, kv, 2 * inner, s.dh, kv + inner, 2 * inner, s.dh, B, s.heads, s.dh, HW,
+                           kv_len, scale, o, inner, o_sp);
             float* y2 = ctx.ws.alloc_f((size_t)M * inner);
             linear_into(ctx, o, inner, M, inner, b.out2, y1, inner, y2, inner, 0, 0, o_sp ? M : 0);
             // x = ff(norm3(x)) + x      (:214)
@@ -402,16 +384,11 @@ struct UNet::Impl {
         const bool sp = split_for_gemm(ctx, C);
         launch_groupnorm(ctx, x.p, C, C, nullptr, 0, 0, B, HW, 32, a.ng, a.nb, 1e-5f, 0, xn, sp);
         float* qkv = ctx.ws.alloc_f((size_t)M * 3 * C);
-        const int i_sp = ctx.tune.attn_split && attn_split_ok(ctx, a.heads, dh) ? 1 : 0;      // [q_h | k_h | v_h] per head, as split32 rows
-        linear_into(ctx, xn, C, M, C, a.qkv, nullptr, 0, qkv, 3 * C, 0, 0, sp ? M : 0, i_sp);
+        linear_into(ctx, xn, C, M, C, a.qkv, nullptr, 0, qkv, 3 * C, 0, 0, sp ? M : 0);
         float* o = ctx.ws.alloc_f((size_t)M * C);
         const float sc = 1.0f / std::sqrt(std::sqrt((float)dh));
-        if (i_sp)
-            attention_into(ctx, qkv, 3 * C, 3 * dh, qkv, 3 * C, 3 * dh, qkv, 3 * C, 3 * dh, B, a.heads, dh, HW, HW, sc * sc, o, C,
-                           0, 0, 1, 0, dh, 2 * dh);
-        else
-            attention_into(ctx, qkv, 3 * C, 3 * dh, qkv + dh, 3 * C, 3 * dh, qkv + 2 * dh, 3 * C, 3 * dh, B, a.heads, dh, HW,
-                           HW, sc * sc, o, C);
+        attention_into(ctx, qkv, 3 * C, 3 * dh, qkv + dh, 3 * C, 3 * dh, qkv + 2 * dh, 3 * C, 3 * dh, B, a.heads, dh, HW,
+                       HW, sc * sc, o, C);
         linear_into(ctx, o, C, M, C, a.proj, x.p, C, out.p, C);
         ctx.ws.release(mk);
         return out;
@@ -554,12 +531,10 @@ void UNet::set_context(Ctx& ctx, const float* context, int B, int L) {
         }
         m.kv_cap_rows = rows;
     }
-    m.kv_split_on = ctx.tune.attn_split && ctx.dtype != 0;
     for (const STW& s : m.st)
         for (const STBlockW& b : s.blocks)
             linear_into(ctx, context, m.cfg.context_dim, (long long)rows, m.cfg.context_dim, b.kv2, nullptr, 0,
-                        m.kv_cache[b.kv_slot], 2 * s.heads * s.dh, 0, 0, 0,
-                        m.kv_split_on && Impl::attn_split_ok(ctx, s.heads, s.dh) ? 1 : 0);
+                        m.kv_cache[b.kv_slot], 2 * s.heads * s.dh);
     m.kv_batch = B;
     m.kv_len = L;
     context_ptr = context;
@@ -571,7 +546,7 @@ void UNet::graph_key(std::vector<unsigned long long>& key) const {
     key.push_back(m.serial);                 // (a later UNet may be constructed at a freed one's address)
     key.push_back((unsigned long long)reinterpret_cast<uintptr_t>(context_ptr));
     key.push_back((unsigned long long)m.kv_batch);
-    key.push_back((unsigned long long)m.kv_len * 2 + (m.kv_split_on ? 1 : 0));
+    key.push_back((unsigned long long)m.kv_len);
     for (const float* p : m.kv_cache) key.push_back((unsigned long long)reinterpret_cast<uintptr_t>(p));
 }
 

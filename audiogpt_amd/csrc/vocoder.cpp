@@ -342,6 +342,14 @@ struct Vocoder::Impl {
                         conv1d(ctx, act, rb.c1[mth], 0.f, nullptr, 1.f, 0, t1);
                         launch_snake_aa(ctx, t1.p, B, L, u.cout, rb.inv_beta[2 * mth + 1], rb.alpha[2 * mth + 1], act.p);
                     } else {
+                        // narrow stages (C = 32 / 64): the pair in one launch, xt stays in LDS (halo_conv1d.hip)
+                        T4& dstp = last ? xs : ((cur.p == bufA.p) ? bufB : bufA);
+                        if (!cur.split && cur.ld == 0 &&
+                            launch_halo_pair(ctx, cur.p, B, L, u.cout, rb.c1[mth].w, rb.c1[mth].k, rb.c1[mth].dil, 0.1f, rb.c2[mth].w,
+                                             rb.c2[mth].k, rb.c2[mth].dil, 0.1f, cur.p, last ? inv_n : 1.f, last ? (j > 0) : 0, dstp.p)) {
+                            if (!last) cur = dstp;
+                            continue;
+                        }
                         conv1d(ctx, cur, rb.c1[mth], 0.1f, nullptr, 1.f, 0, t1);
                     }
                     const T4& in2 = big ? act : t1;

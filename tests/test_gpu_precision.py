@@ -132,54 +132,6 @@ class _env:
         reload_tuning()
 
 
-@pytest.mark.parametrize("B,heads,dh,Nq,Nk", [(2, 8, 40, 780, 780), (2, 8, 40, 780, 77), (2, 8, 80, 195, 195), (2, 8, 80, 195, 77),
-                                              (3, 16, 32, 195, 1), (1, 8, 40, 1060, 1060), (2, 4, 64, 130, 33), (1, 8, 80, 265, 265),
-                                              (1, 8, 40, 12, 45)])
-def test_attention_with_split32_inputs(ctx, B, heads, dh, Nq, Nk):
-    """The form the UNet runs since round 5: q / k / v handed to the fused kernel as split32 rows (MAA_OP_PRESPLIT=1 packs them
-    before the launch; in the models the projections' epilogues write them), no hi / lo split inside the kernel, the softmax
-    scale applied to the scores instead of to Q -- against the same fp32 reference and tolerance as the fp32-input form."""
-    Cc = heads * dh
-    q = torch.randn(B, Nq, Cc, generator=g(34))
-    k = torch.randn(B, Nk, Cc, generator=g(35))
-    v = torch.randn(B, Nk, Cc, generator=g(36))
-    alpha = dh ** -0.5
-
-    def split(t):
-        return t.reshape(B, t.shape[1], heads, dh).permute(0, 2, 1, 3)
-    sim = torch.einsum("bhid,bhjd->bhij", split(q), split(k)) * alpha
-    ref = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), split(v)).permute(0, 2, 1, 3).reshape(B, Nq, Cc)
-    with _env(MAA_OP_PRESPLIT="1"):
-        y = ctx.op_attention(q, k, v, heads, alpha)
-        y2 = ctx.op_attention(q, k, v, heads, alpha)
-    assert torch.equal(y.cpu(), y2.cpu())
-    check(f"{ctx.precision}_attention_split_in_h{heads}_d{dh}_{Nq}x{Nk}", y, ref, TOL[ctx.precision])
-    if ctx.precision == "bf16x3":      # the two input forms differ only in where the scale is applied: ~2^-16 apart
-        y_f = ctx.op_attention(q, k, v, heads, alpha)
-        r, _, _ = rel_err(y, y_f.cpu())
-        assert r <= 5e-5, r
-
-
-def test_unet_with_and_without_split32_attention_inputs(golden, ctx3):
-    """MAA_ATTN_SPLIT=0 restores rounds 1-4's arrangement (fp32 q / k / v rows, split per tile inside the attention kernel): the
-    whole T2A UNet must meet the reference golden either way, and the two agree far inside the gate."""
-    from audiogpt_amd.backend import UNet
-    gu = golden("unet_t2a")
-    x, t, c = torch.from_numpy(gu["x"]), torch.from_numpy(gu["t"]), torch.from_numpy(gu["context"])
-    outs = {}
-    for tag, val in (("split", "1"), ("fp32", "0")):
-        with _env(MAA_ATTN_SPLIT=val):
-            unet = UNet(ctx3, C.UNET_T2A, WT.make_unet_state_dict(C.UNET_T2A, seed=0))
-            ctx3.prof_begin()
-            outs[tag] = unet(x, t, c).cpu()
-            rows = ctx3.prof_end()
-            unet.close()
-        assert "flash_attention" in rows
-        check(f"bf16x3_unet_t2a_attn_{tag}", outs[tag], gu["y"], 1e-4)
-    r, _, _ = rel_err(outs["split"], outs["fp32"])
-    assert 0 < r <= 2e-5, r
-
-
 def _tables(S):
     from oracle import ddim as O
     ac = O.alphas_cumprod(1000, C.LDM_T2A["linear_start"], C.LDM_T2A["linear_end"])
@@ -399,10 +351,14 @@ def test_halo_conv1d_bit_identical_to_the_implicit_gemm(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
     # (third run: BigVGAN's Activation1d through the per-element kernel instead of the tiled one -- same arithmetic and order)
-    for tag, env in (("halo", {}), ("igemm", {"MAA_NO_HALO": "1"}), ("snake_untiled", {"MAA_SNAKE_UNTILED": "1"})):
+    # (fourth run: the MRF pairs of the narrow HiFi-GAN stages as two halo launches instead of the fused pair kernel of round 5,
+    # which is what the first run takes -- the intermediate tensor through LDS instead of through memory, same arithmetic)
+    for tag, env in (("halo", {}), ("igemm", {"MAA_NO_HALO": "1"}), ("snake_untiled", {"MAA_SNAKE_UNTILED": "1"}),
+                     ("two_launches", {"MAA_NO_PAIR": "1"})):
         out = str(tmp_path / f"v_{tag}.npz")
         e = dict(os.environ)
         e.pop("MAA_NO_HALO", None)
+        e.pop("MAA_NO_PAIR", None)
         e.pop("MAA_SNAKE_UNTILED", None)
         e.update(env)
         r = subprocess.run([sys.executable, "-c", _HALO_SCRIPT.format(root=root, out=out)], env=e, capture_output=True,
@@ -413,3 +369,26 @@ def test_halo_conv1d_bit_identical_to_the_implicit_gemm(tmp_path):
         assert np.isfinite(res[0][k]).all()
         for other in res[1:]:
             assert np.array_equal(res[0][k], other[k]), (k, float(np.abs(res[0][k] - other[k]).max()))
+
+
+def test_fused_mrf_pair_is_taken_and_equals_the_two_launches(ctx3):
+    """halo_pair_kernel (c1 -> leaky -> c2 -> + x in one launch, xt kept in LDS) runs the narrow stages of the HiFi-GAN generators
+    by default; MAA_NO_PAIR=1 restores the two launches per pair.  Lengths that put a sample boundary, a one-row tail tile and
+    several tiles per sample (246 / 118 output rows per tile at k = 11) into play; bit-identical waveforms."""
+    from audiogpt_amd.backend import Vocoder
+    gen = torch.Generator().manual_seed(11)
+    for cfg, T in ((C.HIFIGAN_NS_512, 61), (C.HIFIGAN_16K, 5), (C.HIFIGAN_NS_128, 1)):
+        v = Vocoder(ctx3, cfg, WT.make_vocoder_state_dict(cfg, seed=4))
+        mel = torch.clamp(torch.randn(2, 80, T, generator=gen) * 1.5 - 2.25, -6.0, 1.5)
+        ctx3.prof_begin()
+        y = v(mel).cpu()
+        rows = ctx3.prof_end()
+        assert any(k.startswith("halo_pair_bf16x3") for k in rows), rows.keys()
+        with _env(MAA_NO_PAIR="1"):
+            ctx3.prof_begin()
+            y2 = v(mel).cpu()
+            rows2 = ctx3.prof_end()
+        assert not any(k.startswith("halo_pair") for k in rows2) and any(k.startswith("halo_conv1d") for k in rows2), rows2.keys()
+        v.close()
+        assert torch.isfinite(y).all() and torch.equal(y, y2), float((y - y2).abs().max())
+
