@@ -4,6 +4,13 @@
 
 Objects are cached under audiogpt_amd/csrc/_build keyed by source mtime; the shared object is written
 next to this file so that it travels with the repo snapshot to the GPU box.
+
+Diagnostic variants (tracing / sanitizer rows) are separate libraries beside the product one -- they never
+replace it; load one with AUDIOGPT_AMD_LIB=<path>:
+    MAA_BUILD_ROCTX=1      libaudiogpt_mi355x_roctx.so      per-DDIM-step roctx ranges (csrc/ddim.cpp) for rocprofv3 --marker-trace
+    MAA_BUILD_ASAN=1       libaudiogpt_mi355x_asan.so       -fsanitize=address on host AND device code (gfx950:xnack+, -O1 -g): run with
+                                                            HSA_XNACK=1 and LD_PRELOAD=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so)
+    MAA_BUILD_NO_TUNING=1  libaudiogpt_mi355x_notuning.so   deployment build: the MAA_* test / A-B switches compiled out (runtime.cpp)
 """
 import os
 import subprocess
@@ -15,14 +22,25 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libaudiogpt_mi355x.so")
 SOURCES = ["igemm_f32.hip", "igemm_bf16.hip", "igemm_dma.hip", "igemm_dma2.hip", "igemm_pp.hip", "calib.hip", "nsf.hip", "diffsinger.hip", "halo_conv1d.hip", "encoders.hip", "spectral.hip", "flash_attn.hip", "norm.hip", "misc.hip", "runtime.cpp", "blocks.cpp", "unet.cpp", "vae.cpp",
            "vocoder.cpp", "diffnet.cpp", "encoders.cpp", "clap_audio.cpp", "ddim.cpp", "api.cpp"]
+ARCH = "gfx950"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form"]
 LINK = []
+VARIANT = ""
 if os.environ.get("MAA_BUILD_ROCTX") == "1":      # per-DDIM-step roctx ranges (csrc/ddim.cpp) for rocprofv3 --marker-trace
     FLAGS = FLAGS + ["-DMAA_ROCTX"]
     LINK = ["-L/opt/rocm/lib", "-lroctx64"]
+    VARIANT += "_roctx"
+if os.environ.get("MAA_BUILD_ASAN") == "1":       # address sanitizer, host and device (the device side needs xnack+ code objects)
+    ARCH = "gfx950:xnack+"
+    FLAGS = ["--offload-arch=" + ARCH, "-O1", "-g"] + FLAGS[2:] + ["-fsanitize=address", "-shared-libsan"]
+    LINK = LINK + ["-fsanitize=address", "-shared-libsan"]
+    VARIANT += "_asan"
 if os.environ.get("MAA_BUILD_NO_TUNING") == "1":  # deployment build: the MAA_* test / A-B switches are compiled out (runtime.cpp)
     FLAGS = FLAGS + ["-DMAA_NO_TUNING"]
+    VARIANT += "_notuning"
+if VARIANT:
+    OUT = os.path.join(HERE, "libaudiogpt_mi355x%s.so" % VARIANT)
 
 
 def _hipcc():
@@ -56,7 +74,7 @@ def build(force=False, verbose=True):
     if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
         return OUT
     hipcc = _hipcc()
-    bdir = os.path.join(CSRC, "_build")
+    bdir = os.path.join(CSRC, "_build" + VARIANT)
     os.makedirs(bdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "maa.h"))
@@ -80,12 +98,12 @@ def build(force=False, verbose=True):
 
     if jobs:
         if verbose:
-            print("[audiogpt_amd.build] compiling %d file(s) for gfx950" % len(jobs), flush=True)
+            print("[audiogpt_amd.build] compiling %d file(s) for %s%s" % (len(jobs), ARCH, " (%s)" % VARIANT[1:] if VARIANT else ""), flush=True)
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(bdir, s + ".o") for s in SOURCES]
     if jobs or not os.path.exists(OUT):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + LINK
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs + LINK
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-8000:])

@@ -34,6 +34,10 @@ LABELS = {  # bench.py / maa_prof label -> (rocprof kernel prefixes, prefix whos
     "igemm_bf16x3<128x64>": (["igemm_bf16_kernel<128, 64, 2, 2, 3"], "igemm_bf16_kernel<128, 64, 2, 2, 3"),
     "igemm_bf16x3<64x64>": (["igemm_bf16_kernel<64, 64, 2, 2, 3"], "igemm_bf16_kernel<64, 64, 2, 2, 3"),
     "igemm_bf16x3<256x32>": (["igemm_bf16_kernel<256, 32, 4, 1, 3"], "igemm_bf16_kernel<256, 32, 4, 1, 3"),
+    "halo_conv1d_bf16x3<64>": (["halo_conv1d_kernel<64"], "halo_conv1d_kernel<64"),
+    "halo_conv1d_bf16x3<32>": (["halo_conv1d_kernel<32"], "halo_conv1d_kernel<32"),
+    "halo_pair_bf16x3<64>": (["halo_pair_kernel<64"], "halo_pair_kernel<64"),
+    "halo_pair_bf16x3<32>": (["halo_pair_kernel<32"], "halo_pair_kernel<32"),
     "igemm_f32<64x64>": (["igemm_f32_kernel<64, 64"], "igemm_f32_kernel<64, 64"),
     "igemm_f32<128x64>": (["igemm_f32_kernel<128, 64"], "igemm_f32_kernel<128, 64"),
     "igemm_f32<128x128>": (["igemm_f32_kernel<128, 128"], "igemm_f32_kernel<128, 128"),
