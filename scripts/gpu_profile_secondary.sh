@@ -7,7 +7,7 @@ tag=${1:-r3}; prec=${2:-bf16x3}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-for wl in hifigan64 mixed; do
+for wl in ${WORKLOADS:-hifigan64 mixed}; do
   if [ $wl = mixed ]; then steps="--steps 1 --warmup 1"; pmc_args="--steps 1 --warmup 0 --ddim-steps 4 --no-graph"; else steps="--steps 2 --warmup 1"; pmc_args="--steps 1 --warmup 0"; fi
   timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag}_$wl -o bench -- python bench.py --workload $wl $steps --precision $prec --no-cpu-baseline > gpurun_out/${tag}_${wl}_bench_under_rocprof.json 2> gpurun_out/${tag}_${wl}_prof.err
   python scripts/prof_summary.py gpurun_out/prof_${tag}_$wl/bench_results.db > gpurun_out/${tag}_${wl}_kernel_stats.txt
