@@ -6,7 +6,7 @@ tag=${1:-r2}; prec=${2:-bf16x3}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o bench -- python bench.py --steps 1 --warmup 1 --inflight 1 --precision $prec --no-cpu-baseline --no-secondary > gpurun_out/${tag}_${prec}_bench_under_rocprof.json 2> gpurun_out/bench_prof_$tag.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o bench -- python bench.py --steps 1 --warmup 1 --inflight 1 --cfg-split 0 --precision $prec --no-cpu-baseline --no-secondary > gpurun_out/${tag}_${prec}_bench_under_rocprof.json 2> gpurun_out/bench_prof_$tag.err
 python scripts/prof_summary.py gpurun_out/prof_$tag/bench_results.db > gpurun_out/${tag}_${prec}_kernel_stats.txt
 python scripts/rocprof_shapes.py gpurun_out/prof_$tag/bench_results.db 300 > gpurun_out/${tag}_${prec}_kernel_shapes.txt
 rm -rf gpurun_out/prof_$tag

@@ -12,6 +12,8 @@ from bench import synth_conditioning, LATENT, CFG_SCALE  # noqa: E402
 prec = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 pipe = MakeAnAudio("cuda:0", precision=prec)
+pipe.ctx.set_cfg_split(False)      # the arrangement of bench.py's roofline pass (the headline's replicas): a CFG step on ONE stream, so the
+                                   # launches per DDIM step match and attach_traffic accepts the tables (the library default is two lanes)
 n = 8
 x_T = torch.from_numpy(np.random.RandomState(55).randn(n, *LATENT)).float().cuda()
 c = synth_conditioning(n, 1234).cuda()
