@@ -485,3 +485,50 @@ def test_box_class_thresholds():
     assert bench.box_class(dict(fast, l2_read_gbs=15000.0)) == "slow(l2_read_gbs)"
     assert bench.box_class(dict(fast, infinity_cache_read_gbs=4000.0, l2_read_gbs=1.0)) == "slow(l2_read_gbs,infinity_cache_read_gbs)"
     assert bench.box_class({"error": "x"}) is None and bench.box_class(None) is None
+
+
+def test_committed_traffic_table_matches_the_shipped_sources_and_the_headlines_launch_mix():
+    """What the round-5 validation tripped over: the counter passes had run with the library's default two CFG lanes (48 half-size
+    convolutions per DDIM step) while bench.py's roofline pass runs a CFG step on one stream (24), so attach_traffic refused the
+    table and the line said `traffic: null`.  The committed table must carry the hash of the sources that ship, the dominant
+    kernel at the headline's 24 launches per step, and the profile scripts must ask for the headline's arrangement."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from audiogpt_amd.build import _source_hash
+    t = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert t["source_hash"] == _source_hash(), "profiles/pmc_traffic.json was measured on other sources: re-run scripts/gpu_profile.sh"
+    e = t["kernels"]["igemm_pp_bf16x3<256x160,splitK>"]
+    assert e["launches_per_ddim_step"] == 24.0 and e["hbm_bytes_per_launch"] > 0 and 0 < e["mfma_busy"] < 1
+    # bench.attach_traffic accepts it for a roofline record of the headline's shape (2400 launches over 100 steps) ...
+    roof = {"kernel": "igemm_pp_bf16x3<256x160,splitK>", "launches": 2400, "traffic": None}
+    bench.attach_traffic(roof, "bf16x3", None, 100)
+    assert roof["traffic"] == e["hbm_bytes_per_launch"] and roof["mfma_busy"] == e["mfma_busy"] and "NOT measured in this run" in roof["traffic_note"]
+    # ... and refuses it for the two-lane arrangement's launch count
+    lanes = {"kernel": "igemm_pp_bf16x3<256x160,splitK>", "launches": 4800, "traffic": None}
+    bench.attach_traffic(lanes, "bf16x3", None, 100)
+    assert lanes["traffic"] is None and "does not match" in lanes["traffic_note"]
+    assert "set_cfg_split(False)" in open(os.path.join(ROOT, "scripts", "pmc_workload.py")).read()
+    assert "--inflight 1 --cfg-split 0" in open(os.path.join(ROOT, "scripts", "gpu_profile.sh")).read()
+    sec = t.get("secondary", {}).get("hifigan64")
+    assert sec and sec["source_hash"] == _source_hash() and sec["kernels"]["igemm_pp_bf16x3<256x128>"]["launches_per_unit"] == 36.0
+
+
+def test_round5_record_slims_to_the_committed_line():
+    """The full record of the round-5 validation run (profiles/r5_bf16x3_bench_detail.json) -> the stdout line: within the limit,
+    the literal configs[1] number (one batch owning the GPU, both CFG forms, bit-identical), box.class and every secondary value."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r5_bf16x3_bench_detail.json")))
+    line = bench.slim_line(full, "gpurun_out/bench_detail.json")
+    assert len(line) <= bench.LINE_LIMIT
+    d = json.loads(line)
+    shipped = json.load(open(os.path.join(ROOT, "profiles", "r5_bf16x3_bench.json")))
+    assert d["value"] == shipped["value"] and d["one_batch_in_flight"] == shipped["one_batch_in_flight"]
+    assert d["one_batch_in_flight"]["cfg_lanes"] == 2 and d["one_batch_other_form"]["cfg_lanes"] == 1 and d["one_batch_other_form"]["bit_identical"] is True
+    assert d["box"]["class"] == "fast" and d["config"]["cfg_lanes"] == 1 and d["config"]["batches_in_flight"] == 3
+    assert {k: v["value"] for k, v in d["secondary"].items()} == {k: v["value"] for k, v in shipped["secondary"].items()}
+    assert d["secondary"]["t2a_bf16"]["roofline"]["kernel"].startswith("igemm_dma_bf16<")      # the shipped engines' one-product form
