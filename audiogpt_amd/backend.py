@@ -354,8 +354,20 @@ class UNet:
             a.d_log_x, a.d_log_x0 = logs[0].data_ptr(), logs[1].data_ptr()
         with self.ctx.lock:
             L.check(self.ctx.lib.maa_ddim_sample(self.ctx.h, self.h, C.byref(a), L.dptr(x)))
-        if logs is not None:
-            return x, logs[0].clone(), logs[1].clone()
+            if logs is not None:
+                # the slabs are shared by every call on this model: copy them out before the lock is released, ordered behind the
+                # context's own stream (a private torch stream: copy on it; a library-created blocking stream orders against
+                # torch's default stream by itself, but a caller on another stream must wait, so drain it)
+                if self.ctx._stream is not None:
+                    with torch.cuda.stream(self.ctx._stream):
+                        out = (logs[0].clone(), logs[1].clone())
+                    for t in out:
+                        t.record_stream(torch.cuda.current_stream(dev))
+                    torch.cuda.current_stream(dev).wait_stream(self.ctx._stream)
+                else:
+                    self.ctx.synchronize()
+                    out = (logs[0].clone(), logs[1].clone())
+                return x, out[0], out[1]
         return x
 
     def close(self):
@@ -757,7 +769,7 @@ class Resampler:
     def __init__(self, ctx, orig, new, width, kernels):
         self.ctx = ctx
         kt, kp = L.host_f32(torch.as_tensor(kernels))
-        self.orig, self.new = int(orig), int(new)
+        self.orig, self.new, self.width = int(orig), int(new), int(width)
         if kt.dim() != 2 or kt.shape[0] != self.new or kt.shape[1] != 2 * width + self.orig:
             raise L.MaaError("Resampler: kernel bank %s must be [new, 2 width + orig]" % (tuple(kt.shape),))
         h = C.c_void_p()

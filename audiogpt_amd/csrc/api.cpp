@@ -171,7 +171,8 @@ int maa_ctx_set_stream(maa_ctx* ctx, void* hip_stream) {
 int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out) {
     return guarded([&] {
         MAA_CHECK(ctx && out, "null argument");
-        *out = ctx->c.ws.capacity();
+        // the second CFG lane (ddim.cpp) owns a workspace of its own, about half a batch's UNet arena, which is kept once it exists
+        *out = ctx->c.ws.capacity() + (ctx->c.side ? ctx->c.side->ws.capacity() : 0);
     });
 }
 

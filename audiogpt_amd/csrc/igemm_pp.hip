@@ -511,7 +511,10 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     q.Nb = Nb;
     q.part = pl.S > 1 ? part : nullptr;
     q.S = pl.S;
-    q.tile_major = ctx.tune.xcd_align && pl.S > 1 ? 1 : 0;
+    // slice-major items (rounds 3 - 4, again since round 6): an XCD's contiguous eighth of the items is part of ONE K slice, so its
+    // L2 streams 1 / S of the packed weights; tile-major (round 5's default) gave it a few tiles with ALL their slices and every L2
+    // streamed the whole weight tensor: FETCH_SIZE x 3.4 at the 5 x 39 level for the same run time (profiles/r5_bf16x3_pmc_fetch_write.txt)
+    q.tile_major = ctx.tune.pp_tile_major && pl.S > 1 ? 1 : 0;
     q.dbg = ctx.tune.pp_dbg >= 0 ? ctx.tune.pp_dbg : 0;
     MAA_CHECK((q.nci + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
     MAA_CHECK(q.CAPl > 0, "igemm_pp: the A ring does not fit beside the weight ring");
@@ -783,7 +786,7 @@ PPPlan igemm_pp_plan(const Ctx& ctx, const IGemm& p) {
             // enough (slice, tile) items for one round of ~200 workgroups at the UNet's two resolutions without the slab round
             // trip outgrowing the contraction
             const int ntiles = (p.N + bn - 1) / bn;
-            S = ntiles >= 4 ? 4 : 2;
+            S = ntiles >= 4 ? ctx.tune.pp_s_wide : ctx.tune.pp_s_narrow;
         }
     }
     if (S > nci) S = nci;

@@ -131,6 +131,8 @@ struct Tuning {
     std::map<int, std::string> dma2_n;      // MAA_DMA2_N<packed N>
     bool dma2_persist = true;               // MAA_DMA2_PERSIST=0: one workgroup per work item
     std::string pp, pp1;                    // MAA_PP / MAA_PP1 = "off" | "bn,S"
+    int pp_s_narrow = 2, pp_s_wide = 4;     // MAA_PP_S = "a,b": K slices of the ping-pong engine's 3x3 layers with < 4 / >= 4 N tiles (10x78 / 5x39 in the UNet)
+    bool pp_tile_major = false;             // MAA_PP_TILE_MAJOR=1: round 5's item order (a tile's K slices are neighbours); 0: slice-major (an XCD streams 1 / S of the weights)
     int pp_dbg = -1;                        // MAA_PP_DBG: ablation mask of igemm_pp's TUNE instantiation (-1: product kernel)
     bool op_presplit = false;               // MAA_OP_PRESPLIT=1: the maa_op_* test entry points hand activations over as split32
     int dma_ns_low = 3;                     // MAA_DMA_NS_LOW: LDS stages of a 64x64 LDS-DMA launch with < 2.5 workgroups per CU (2: as the others)

@@ -165,6 +165,13 @@ void Tuning::load() {
     }
     const std::string pe = get_s("MAA_DMA2_PERSIST");
     dma2_persist = pe.empty() || pe[0] != '0';
+    pp_s_narrow = 2;
+    pp_s_wide = 4;
+    const std::string pss = get_s("MAA_PP_S");
+    if (!pss.empty()) std::sscanf(pss.c_str(), "%d,%d", &pp_s_narrow, &pp_s_wide);
+    if (pp_s_narrow < 1) pp_s_narrow = 1;
+    if (pp_s_wide < 1) pp_s_wide = 1;
+    pp_tile_major = get_s("MAA_PP_TILE_MAJOR") == "1";
     const std::string pd = get_s("MAA_PP_DBG");
     pp_dbg = pd.empty() ? -1 : std::atoi(pd.c_str());
     const std::string ps = get_s("MAA_OP_PRESPLIT");

@@ -24,8 +24,16 @@ They are restated below from librosa's published algorithm; tests/test_host_logi
 scipy.signal.stft framing, analytic tones, the filter bank's defining properties, and against `transformers.audio_utils`
 (an independent implementation of the same two librosa routines: filter bank equal to 1e-9, |STFT| to 1e-6 relative) --
 not against librosa itself.
-`librosa.resample` (resampy "kaiser_best" in 0.9.2) is replaced by scipy.signal.resample_poly when the input is not
-already at 16 kHz -- a different (polyphase Kaiser) low-pass; at 16 kHz no resampling happens, as in the reference.
+`librosa.resample(y, orig_sr=sr, target_sr=16000)` (audio-chatgpt.py:462, 482; librosa 0.9.x: res_type "kaiser_best" =
+resampy 0.2.2, pinned in requirements.txt:52) is restated too -- `resampy_filter`, `resampy_kernel_bank`, `librosa_resample`:
+resampy's band-limited sinc interpolation (J. O. Smith's algorithm) with its published "kaiser_best" design (64 zero crossings,
+512 table entries per crossing, Kaiser window beta = 14.769656459379492, roll-off 0.9475937167399596), the table linearly
+interpolated at each tap, zero extension at both ends, int(n ratio) outputs, then librosa's fix_length to ceil(n ratio) (a zero
+sample when the two differ) and no rescaling.  For a rational ratio the interpolated taps repeat with the period new / gcd, so
+the whole routine is a bank of `new` FIR phases applied every `orig` input samples -- the strided contraction the library's
+resampler (`maa_resampler_*`) runs; `DeviceMelTransform` feeds it this bank.  tests/test_host_logic.py checks the bank against
+the scalar time-register loop of oracle/resampy.py (the algorithm as resampy states it), tones, and scipy's polyphase resampler
+(a different Kaiser low-pass: agreement to the pass-band ripple, stated there); resampy itself is absent: PARITY UNPINNED.
 """
 import os
 
@@ -119,25 +127,154 @@ def dft_basis(n_fft=N_FFT, window="hann"):
     return np.concatenate([np.cos(ang) * win, -np.sin(ang) * win], axis=0).astype(np.float32)
 
 
-def prepare_wav(input_audio):
-    """The host half of Inpaint.gen_mel_audio (audio-chatgpt.py:473-489): (sr, int16 samples, mono or [n, 2] stereo) ->
-    float32 mono at 16 kHz, zero-extended / cropped to the clip length."""
-    sr, wav = input_audio
+RESAMPY_FILTERS = {      # resampy 0.2.2 filters.py: the published designs behind data/kaiser_best.npz / kaiser_fast.npz
+    "kaiser_best": dict(num_zeros=64, precision=9, beta=14.769656459379492, rolloff=0.9475937167399596),
+    "kaiser_fast": dict(num_zeros=16, precision=9, beta=8.555504641634386, rolloff=0.85),
+}
+_RESAMPY_CACHE = {}
+
+
+def resampy_filter(name="kaiser_best"):
+    """resampy.filters.sinc_window(num_zeros, precision, window=kaiser(beta), rolloff): the right half of the windowed sinc
+    sampled 2**precision times per zero crossing -> (half_window float64 [num_zeros 2**precision + 1], 2**precision)."""
+    if name not in _RESAMPY_CACHE:
+        from scipy.signal.windows import kaiser
+        f = RESAMPY_FILTERS[name]
+        num_bits = 2 ** f["precision"]
+        n = num_bits * f["num_zeros"]
+        sinc_win = f["rolloff"] * np.sinc(f["rolloff"] * np.linspace(0, f["num_zeros"], num=n + 1, endpoint=True))
+        taper = kaiser(2 * n + 1, f["beta"])[n:]
+        _RESAMPY_CACHE[name] = (taper * sinc_win, num_bits)
+    return _RESAMPY_CACHE[name]
+
+
+def resampy_kernel_bank(sr_orig, sr_new, filter="kaiser_best"):
+    """resampy.resample(x, sr_orig, sr_new, filter) as a polyphase bank: -> (kernels float32 [new, 2 width + orig], width)
+    with orig / new divided by their gcd, in the layout of `clap.sinc_resample_kernel` (output q new + p is the dot product
+    of kernels[p] with the input samples q orig - width ... q orig + orig + width - 1, zeros outside the signal).  Phase p
+    sits at time p orig / new: n = floor, frac = scale (time - n); left-wing tap i multiplies x[n - i] by the table at
+    frac 2**precision + i index_step, right-wing tap k multiplies x[n + 1 + k] by the table at (scale - frac) 2**precision +
+    k index_step, each linearly interpolated between table entries (resampy/interpn.py:resample_f)."""
+    from math import gcd
+    g = gcd(int(sr_orig), int(sr_new))
+    orig, new = int(sr_orig) // g, int(sr_new) // g
+    win, num_table = resampy_filter(filter)
+    sample_ratio = float(sr_new) / float(sr_orig)
+    win = win * sample_ratio if sample_ratio < 1 else win.copy()
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    scale = min(1.0, sample_ratio)
+    index_step = int(scale * num_table)
+    nwin = win.shape[0]
+    width = nwin // index_step + 1
+    bank = np.zeros((new, 2 * width + orig), dtype=np.float64)
+    for p in range(new):
+        time = p * orig / new
+        n = (p * orig) // new
+        frac = scale * (time - n)
+        for wing, f in ((0, frac), (1, scale - frac)):
+            index_frac = f * num_table
+            offset = int(index_frac)
+            eta = index_frac - offset
+            idx = offset + index_step * np.arange((nwin - offset) // index_step)
+            w = win[idx] + eta * delta[idx]
+            taps = np.arange(idx.shape[0])
+            cols = width + (n - taps if wing == 0 else n + 1 + taps)
+            bank[p, cols] += w
+    return bank.astype(np.float32), width
+
+
+def resampy_carry_kernel(sr_orig, sr_new, filter="kaiser_best"):
+    """The one place where resampy is NOT periodic in the output index.  Its time register is a running float64 sum of
+    1 / ratio; where the exact time is an integer N (outputs q new) the sum may land a few ulps below it, and then n = N - 1 and
+    frac = scale (1 - eps) instead of n = N, frac = 0.  With an ideal table the two are the same point of a continuous filter,
+    but resampy steps through its table by the TRUNCATED index_step = int(scale 2**precision), so the left wing then sits a
+    fraction of a table entry further out (a 1e-4-level difference).  -> the kernel [1, 2 width + orig] of that case in the
+    window layout of `resampy_kernel_bank`; `resampy_carries` says which outputs take it (none when 1 / ratio is exact in
+    binary: 48 / 32 / 24 / 8 kHz)."""
+    from math import gcd
+    g = gcd(int(sr_orig), int(sr_new))
+    orig, new = int(sr_orig) // g, int(sr_new) // g
+    sample_ratio = float(sr_new) / float(sr_orig)
+    win, num_table = resampy_filter(filter)
+    win = win * sample_ratio if sample_ratio < 1 else win.copy()
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    scale = min(1.0, sample_ratio)
+    index_step = int(scale * num_table)
+    nwin = win.shape[0]
+    width = nwin // index_step + 1
+    k = np.zeros((1, 2 * width + orig), dtype=np.float64)
+    index_frac = scale * num_table                                  # left wing at frac -> scale: x[N - 1 - i]
+    offset = int(index_frac)
+    idx = offset + index_step * np.arange((nwin - offset) // index_step)
+    k[0, width - 1 - np.arange(idx.shape[0])] += win[idx] + (index_frac - offset) * delta[idx]
+    idx = index_step * np.arange(nwin // index_step)                # right wing at frac -> 0: x[N + k]
+    k[0, width + np.arange(idx.shape[0])] += win[idx]
+    return k.astype(np.float32)
+
+
+def resampy_carries(n_out, sr_orig, sr_new):
+    """Output indices t (multiples of new / gcd) at which resampy's running time register int()s to one less than the
+    exact sample index (see `resampy_carry_kernel`)."""
+    from math import gcd
+    g = gcd(int(sr_orig), int(sr_new))
+    orig, new = int(sr_orig) // g, int(sr_new) // g
+    inc = 1.0 / (float(sr_new) / float(sr_orig))
+    if n_out <= new:
+        return np.zeros(0, dtype=np.int64)
+    reg = np.cumsum(np.full(n_out - 1, inc))                        # reg[t - 1] = the register before output t (sequential adds)
+    t = np.arange(new, n_out, new)
+    return t[reg[t - 1].astype(np.int64) != (t // new) * orig]
+
+
+def librosa_resample(wav, sr_orig, sr_new=SAMPLE_RATE, filter="kaiser_best"):
+    """librosa.resample(wav, orig_sr, target_sr) of librosa 0.9.x (res_type "kaiser_best", fix=True, scale=False) for a 1-D
+    float32 signal, in numpy: the kernel bank applied as a strided contraction (the arithmetic of the device path)."""
+    from math import gcd
+    wav = np.asarray(wav, dtype=np.float32)
+    if int(sr_orig) == int(sr_new):
+        return wav
+    g = gcd(int(sr_orig), int(sr_new))
+    orig, new = int(sr_orig) // g, int(sr_new) // g
+    k, width = resampy_kernel_bank(sr_orig, sr_new, filter)
+    ratio = float(sr_new) / float(sr_orig)
+    n_resampy, n_fixed = int(wav.shape[0] * ratio), int(np.ceil(wav.shape[0] * ratio))
+    q = -(-n_fixed // new)
+    xp = np.zeros(width + q * orig + orig + width, dtype=np.float32)
+    m = min(wav.shape[0], q * orig + orig + width)
+    xp[width:width + m] = wav[:m]
+    frames = np.lib.stride_tricks.sliding_window_view(xp, k.shape[1])[::orig][:q]
+    out = (frames @ k.T).reshape(-1)[:n_fixed].astype(np.float32)
+    t = resampy_carries(n_resampy, sr_orig, sr_new)
+    if t.size:
+        out[t] = frames[t // new] @ resampy_carry_kernel(sr_orig, sr_new, filter)[0]
+    out[n_resampy:] = 0                          # resampy stops at int(n ratio); librosa.util.fix_length zero-pads to ceil
+    return out
+
+
+def to_float_mono(wav):
+    """audio-chatgpt.py:457-460 / 473-480: int16 samples -> float32 / 32768, stereo [n, 2] -> librosa.to_mono (channel mean)."""
     wav = np.asarray(wav).astype(np.float32, order="C") / 32768.0
     if wav.ndim == 2:
-        wav = wav.mean(axis=1)                  # librosa.to_mono
-    if sr != SAMPLE_RATE:
-        from math import gcd
+        wav = wav.mean(axis=1)                  # librosa.to_mono(wav.T)
+    return wav
 
-        from scipy.signal import resample_poly
-        g = gcd(int(sr), SAMPLE_RATE)
-        wav = resample_poly(wav, SAMPLE_RATE // g, int(sr) // g).astype(np.float32)
+
+def fit_clip(wav):
+    """audio-chatgpt.py:464-469 / 484-489: crop to 848 * 256 samples; a shorter clip is zero-extended by a FULL clip length
+    (the reference's `np.pad(ori_wav, (0, mel_len * hop_size))`), so its frame count depends on the input -- reproduced."""
     input_len = MEL_LEN * HOP
     if len(wav) < input_len:
-        wav = np.pad(wav, (0, input_len), constant_values=0)
-    else:
-        wav = wav[:input_len]
-    return wav
+        return np.pad(wav, (0, input_len), constant_values=0)
+    return wav[:input_len]
+
+
+def prepare_wav(input_audio):
+    """The host restatement of Inpaint.gen_mel_audio up to the mel (audio-chatgpt.py:473-489): (sr, int16 samples, mono or
+    [n, 2] stereo) -> float32 mono at 16 kHz, zero-extended / cropped to the clip length."""
+    sr, wav = input_audio
+    return fit_clip(librosa_resample(to_float_mono(wav), sr, SAMPLE_RATE))
 
 
 def gen_mel_audio(input_audio):
@@ -157,12 +294,54 @@ class DeviceMelTransform:
         cfg = dict(n_fft=N_FFT, hop=HOP, n_mels=N_MELS, pad_mode=self.pad_mode, power=1, log_kind="transforms_16000",
                    amin=1e-5, ref=1.0, out_layout="bmt")
         self.spectral = Spectral(ctx, cfg, dft_basis(N_FFT), mel_filterbank())
+        self._resamplers = {}
 
     def mel(self, wav):
         """float waveform [n] or [B, n] at 16 kHz -> device tensor [B, 80, 1 + n // 256] in [0, 1]."""
         return self.spectral.forward(wav)
 
-    def __call__(self, sr, wav):
+    def resample(self, x, sr):
+        """librosa.resample(x, orig_sr=sr, target_sr=16000) on the device: resampy's kaiser_best as the library's polyphase
+        contraction (`resampy_kernel_bank`), the last sample zeroed where resampy's int(n ratio) falls short of librosa's
+        ceil(n ratio).  x: device tensor [n]."""
+        from math import gcd
+
         import torch
-        x = torch.from_numpy(np.ascontiguousarray(prepare_wav((sr, wav))))
-        return self.mel(x)[0].cpu().numpy()
+
+        from .backend import Resampler
+        sr = int(sr)
+        if sr == SAMPLE_RATE:
+            return x
+        g = gcd(sr, SAMPLE_RATE)
+        orig, new = sr // g, SAMPLE_RATE // g
+        r = self._resamplers.get(sr)
+        if r is None:
+            k, width = resampy_kernel_bank(sr, SAMPLE_RATE)
+            r = self._resamplers[sr] = Resampler(self.spectral.ctx, orig, new, width, k)
+        n = x.shape[-1]
+        x = x.contiguous()
+        y = r.forward(x)[0]
+        ratio = float(SAMPLE_RATE) / float(sr)
+        n_resampy, n_fixed = int(n * ratio), int(np.ceil(n * ratio))
+        y = y[:n_fixed]
+        t = resampy_carries(n_resampy, sr, SAMPLE_RATE)
+        if t.size:                               # the outputs whose running time register fell below its integer: a second,
+            rc = self._resamplers.get((sr, "carry"))    # one-phase pass of the same contraction, scattered into place
+            if rc is None:
+                rc = self._resamplers[(sr, "carry")] = Resampler(self.spectral.ctx, orig, 1, r.width,
+                                                                 resampy_carry_kernel(sr, SAMPLE_RATE))
+            t = torch.from_numpy(t).to(y.device)
+            y[t] = rc.forward(x)[0][t // new]
+        if n_resampy < n_fixed:
+            y[n_resampy:] = 0
+        return y
+
+    def __call__(self, sr, wav):
+        """Inpaint.gen_mel_audio (audio-chatgpt.py:468-491): (sr, int16 samples [n] or [n, 2]) -> numpy [80, frames]; the
+        resampler, the clip fit and the mel all run on the device."""
+        import torch
+        x = torch.from_numpy(np.ascontiguousarray(to_float_mono(wav))).to(self.spectral.ctx.device)
+        x = self.resample(x, sr)
+        input_len = MEL_LEN * HOP
+        x = torch.nn.functional.pad(x, (0, input_len)) if x.shape[0] < input_len else x[:input_len]
+        return self.mel(x.contiguous())[0].cpu().numpy()

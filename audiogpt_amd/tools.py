@@ -1,9 +1,12 @@
 """AudioGPT tool classes T2A / I2A / Inpaint with the reference's Python call signatures
 (audio-chatgpt.py:140-212, 214-273, 418-558), re-pointed at the MI355X backend.
 
-The LangChain agent binds `Tool(func=<obj>.inference)` (audio-chatgpt.py:1084,1114,1120): a single str in, a
-file name out.  Those signatures are kept byte-compatible; the bodies follow the reference line by line but the
-sampler / model / vocoder objects are the HIP-backed ones.  Reference quirks are reproduced deliberately
+The LangChain agent binds `Tool(func=self.t2a.inference)` (audio-chatgpt.py:1084), `Tool(func=self.i2a.inference)` (:1114)
+and, for inpainting, `Tool(func=self.inpaint.show_mel_fn)` (:1120: audio path in, the path of a viridis PNG of its mel out);
+the Gradio callback then calls `Inpaint.inference(input_audio, mel_and_mask)` (:537).  Those signatures are kept
+byte-compatible.  The method bodies ARE the reference's glue, kept line for line on purpose (they define the RNG order, the
+argument quirks and the file formats the agent sees -- including the `inapint_wav` spelling); what is new is everything
+they call: the sampler / model / vocoder / mel objects are the HIP-backed ones.  Reference quirks are reproduced deliberately
 (SURVEY.md section 0.8): `inference()` ignores its seed/scale/ddim_steps/n_samples arguments and calls
 `txt2audio` with the defaults; `Inpaint.inpaint` builds a seeded start_code and does not pass it.
 
@@ -17,7 +20,7 @@ Pluggable:
     checkpoint's state_dict (then `clap_tokenizer=` supplies the host-side tokenizer); a checkpoint dict that carries
     `clap_model.*` entries builds it too; `scorer=` overrides with any callable (prompt, wav, sr) -> score.  With none of
     them the first sample is returned (the reference always loads CLAP_weights_2022.pth)
-  * wav / image file I/O uses scipy + a minimal PNG/colormap path only if PIL / soundfile are absent
+  * wav files are written with soundfile when it is installed, scipy.io.wavfile otherwise; PNGs with PIL, viridis from matplotlib
 """
 import os
 import uuid
@@ -175,6 +178,8 @@ class Inpaint:
             from .mel import DeviceMelTransform
             mel_transform = DeviceMelTransform(model.ctx)
         self.mel_transform = mel_transform
+        import matplotlib.cm
+        self.cmap_transform = matplotlib.cm.viridis                                   # audio-chatgpt.py:424
 
     def make_batch_sd(self, mel, mask, num_samples=1):
         mel = torch.from_numpy(mel)[None, None, ...].to(dtype=torch.float32)
@@ -185,6 +190,31 @@ class Inpaint:
         masked_mel = masked_mel * 2 - 1
         rep = lambda t: t.to(device=self.device).repeat(num_samples, 1, 1, 1)   # noqa: E731
         return {"mel": rep(mel), "mask": rep(mask), "masked_mel": rep(masked_mel)}
+
+    def gen_mel(self, input_audio_path):
+        """audio-chatgpt.py:452-467: wav file -> [80, frames] mel in [0, 1] (int16 -> float, stereo -> mono, librosa.resample
+        to 16 kHz, crop / zero-extend to the clip length, TRANSFORMS_16000 -- all inside `self.mel_transform`)."""
+        from scipy.io import wavfile
+        sr, ori_wav = wavfile.read(input_audio_path)
+        return self.mel_transform(sr, ori_wav)
+
+    def gen_mel_audio(self, input_audio):
+        """audio-chatgpt.py:468-491: the same for the `(sr, samples)` pair Gradio hands over."""
+        sr, ori_wav = input_audio
+        return self.mel_transform(sr, ori_wav)
+
+    def show_mel_fn(self, input_audio_path):
+        """The "Audio Inpainting" Tool.func (audio-chatgpt.py:492-499, registered at :1120): audio path -> 'image/<8 hex>.png',
+        the first 500 mel frames through viridis."""
+        from PIL import Image
+        crop_len = 500
+        crop_mel = self.gen_mel(input_audio_path)[:, :crop_len]
+        color_mel = self.cmap_transform(crop_mel)
+        image = Image.fromarray((color_mel * 255).astype(np.uint8))
+        image_filename = os.path.join("image", str(uuid.uuid4())[0:8] + ".png")
+        os.makedirs("image", exist_ok=True)
+        image.save(image_filename)
+        return image_filename
 
     def inpaint(self, batch, seed, ddim_steps, num_samples=1, W=512, H=512):
         model = self.sampler.model
@@ -220,14 +250,13 @@ class Inpaint:
         torch.set_grad_enabled(False)
         show_mel = np.array(Image.open(mel_and_mask["image"]).convert("L")) / 255
         mask = np.array(Image.open(mel_and_mask["mask"]).convert("L")) / 255
-        sr, ori_wav = input_audio
-        input_mel = self.mel_transform(sr, ori_wav)
+        input_mel = self.gen_mel_audio(input_audio)
         inpainted, gen_wav = self.inference_mel(input_mel, mask, seed, ddim_steps)
         inpainted = inpainted[:, :show_mel.shape[1]]
+        color_mel = self.cmap_transform(inpainted)
         input_len = int(input_audio[1].shape[0] * SAMPLE_RATE / input_audio[0])
         gen_wav = (gen_wav * 32768).astype(np.int16)[:input_len]
-        import matplotlib.cm
-        image = Image.fromarray((matplotlib.cm.viridis(inpainted) * 255).astype(np.uint8))
+        image = Image.fromarray((color_mel * 255).astype(np.uint8))
         image_filename = os.path.join("image", str(uuid.uuid4())[0:8] + ".png")
         os.makedirs("image", exist_ok=True)
         image.save(image_filename)

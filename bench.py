@@ -70,9 +70,10 @@ def synth_conditioning(n, seed):
     return torch.nn.functional.layer_norm(torch.randn(n, 77, 1024, generator=g), (1024,))
 
 
-def cpu_baseline(ddim_steps_sample=2):
-    """Time the CPU oracle on this host: 1 latent with CFG, `ddim_steps_sample` of 100 DDIM steps (scaled),
-    plus one full VAE decode and one full HiFi-GAN pass.  Returns audio-seconds per second for one clip."""
+def cpu_baseline(ddim_steps_sample=10):
+    """Time the CPU oracle on this host: 1 latent with CFG, `ddim_steps_sample` of 100 DDIM steps (scaled; 10 = a whole
+    BASELINE configs[0] job), plus one full VAE decode and one full HiFi-GAN pass.  Returns audio-seconds per
+    second for one clip."""
     from oracle import ddim as O_ddim
     from oracle import unet as O_unet
     from oracle import vae as O_vae
@@ -110,6 +111,11 @@ def cpu_baseline(ddim_steps_sample=2):
                 sample="1 prompt: %d of %d CFG DDIM steps timed and scaled (%.2f s/step), + full VAE decode (%.2f s) "
                        "+ full HiFi-GAN 624 frames (%.2f s); torch %s fp32, %d threads"
                        % (ddim_steps_sample, DDIM_STEPS, t_unet, t_vae, t_voc, torch.__version__, cores),
+                # the reference's own classes timed beside this port on the same 8 cores (the reference tree does not travel to the
+                # GPU box): port time / reference time on the 10-step configs[0] job, two runs -- the port is bit-identical in
+                # latent and mel and takes 0.75 - 0.94 x the reference's time, i.e. this baseline slightly flatters the CPU
+                reference_time_ratio={"port_over_reference": [0.75, 0.942], "at_100_steps": [0.70, 0.973],
+                                      "source": "profiles/r5_cpu_reference_vs_port.txt"},
                 parts={"unet_cfg_step_s": t_unet, "vae_decode_s": t_vae, "hifigan_624_s": t_voc})
 
 
@@ -343,12 +349,12 @@ def roofline_of(rows, precision):
     }
 
 
-def attach_traffic(roof, precision, section=None, units=None):
+def attach_traffic(roof, precision, section=None, units=None, table_path=None):
     """HBM-side bytes per launch (and MFMA-busy) of a roofline's dominant kernel from profiles/pmc_traffic.json -- measured by
     scripts/gpu_profile*.sh with rocprofv3 PMC passes on the GPU box right before the bench.  Accepted only if taken on THIS
     binary and launch mix: same sources (hash), same precision, and the same number of launches of that kernel per unit of
     work (`units` of this run: DDIM steps of the headline batch, generator passes / DDIM steps of a secondary workload)."""
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    tpath = table_path or os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(tpath):
         return
     from audiogpt_amd.build import _source_hash
@@ -445,6 +451,8 @@ def slim_line(result, detail_path=None, limit=LINE_LIMIT):
     if result.get("cpu_baseline"):
         o["cpu_baseline"] = _pick(result["cpu_baseline"], _CPU_KEEP)
         o["cpu_baseline"]["sample"] = str(result["cpu_baseline"].get("sample", ""))[:160]
+        if result["cpu_baseline"].get("reference_time_ratio"):
+            o["cpu_baseline"]["reference_time_ratio"] = result["cpu_baseline"]["reference_time_ratio"]["port_over_reference"]
     if result.get("one_batch_in_flight"):
         o["one_batch_in_flight"] = _pick(result["one_batch_in_flight"], ("value", "ms_per_step", "steps", "cfg_lanes"))
     for k in ("one_batch_other_form", "one_batch_two_streams"):      # (the second: records of rounds 3 / 4)
@@ -828,6 +836,25 @@ class _NullEvent:
         return 0.0
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N ...` started without a launcher: re-run this file as N ranks under torch.distributed.run
+    (--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1, a free port), pass the ranks' stdout / stderr through -- rank 0 prints
+    the ONE JSON line -- and exit with the launcher's status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -858,7 +885,8 @@ def main(argv=None):
                          "pipeline replicas / HIP streams, as a serving loop would overlap requests; 1 = strictly one after another")
     ap.add_argument("--cfg-split", default="auto", choices=["auto", "0", "1"],
                     help="classifier-free guidance inside the sampler: 1 = the two halves of a step as two lanes (branches of the "
-                         "captured step graph), 0 = one stream, auto = the library's default (two lanes)")
+                         "captured step graph), 0 = one stream, auto = lanes only when ONE batch is in flight (--inflight 1): with "
+                         "several replicas the chip is already full from outside and six concurrent lanes lose 24 %")
     ap.add_argument("--force-collectives", action="store_true",
                     help="initialise the process group and issue C1 scatter / broadcast, C2 gather, the barriers and ranks_seen even "
                          "with ONE rank (RCCL exercised on the one GPU a test box has: tests/test_gpu_rccl.py)")
@@ -868,10 +896,16 @@ def main(argv=None):
                     help="print the full record on stdout instead of the <= 6 kB line (per-kernel tables included: ~25 kB)")
     args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it: become the launcher (one rank per GPU under torch.distributed.run on
+        # 127.0.0.1, the command the contract names) and hand rank 0's line through; the ranks see WORLD_SIZE and take the path below
+        return self_launch(args.gpus, sys.argv[1:] if argv is None else list(argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with --nproc-per-node == --gpus"
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s): use --nproc-per-node == --gpus (or run "
+                         "`python bench.py --gpus N` without a launcher: it starts its own ranks)" % (args.gpus, world))
     stub = args.stub_cpu
     if stub:
         args.no_roofline = args.no_cpu_baseline = args.no_secondary = True

@@ -72,7 +72,8 @@ int maa_ctx_set_cfg_split(maa_ctx* ctx, int mode);
  * malformed MAA_DMA2 / MAA_DMA2_N<n> value fails here (and in maa_ctx_create) with a message naming the variable.  For tests
  * and A/B runs. */
 int maa_ctx_reload_tuning(maa_ctx* ctx);
-/* bytes currently reserved for the activation workspace */
+/* bytes currently reserved for the activation workspace, the second CFG lane's arena included (it exists once a guided sample()
+ * has run with two lanes and is kept for the context's lifetime) */
 int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out);
 
 /* ---- per-kernel timing (replaces the reference's utils.Timer, NeuralSeq/utils/__init__.py:222-237) ----

@@ -262,6 +262,56 @@ def test_Inpaint_inference_files_in_files_out(tmp_path, monkeypatch):
     assert sr2 == 16000 and data.dtype == np.int16 and data.shape == (12 * sr,)
 
 
+def test_Inpaint_show_mel_fn_is_the_registered_tool(tmp_path, monkeypatch):
+    """`Tool(name="Audio Inpainting", func=self.inpaint.show_mel_fn)` (audio-chatgpt.py:1120, body :492-499, gen_mel :452-467):
+    a wav FILE in, 'image/<8 hex>.png' out -- the first 500 mel frames through viridis.  Files: mono 16 kHz (no resampling),
+    stereo 44.1 kHz (to_mono + the resampy kaiser_best restatement on the device, with its carry outputs), a short mono 8 kHz
+    clip (up-sampling, the reference's full-clip zero extension).  The mel is checked against the scalar time-register
+    restatement (oracle/resampy.py) followed by the numpy TRANSFORMS_16000; the PNG against viridis of that mel."""
+    import re
+
+    import matplotlib.cm
+    from PIL import Image
+    from scipy.io import wavfile
+
+    from audiogpt_amd import mel as M
+    from audiogpt_amd.tools import Inpaint
+    from oracle import resampy as R
+    monkeypatch.chdir(tmp_path)
+    inp = Inpaint("cuda:0")
+    assert inp.cmap_transform is matplotlib.cm.viridis                                   # audio-chatgpt.py:424
+    rs = np.random.RandomState(7)
+    cases = {}
+    t = np.arange(12 * 16000) / 16000
+    cases["mono16k"] = (16000, (0.3 * np.sin(2 * np.pi * (200 + 40 * t) * t) * 32767).astype(np.int16))
+    t = np.arange(6 * 44100) / 44100
+    left = 0.25 * np.sin(2 * np.pi * (300 + 500 * t) * t) + 0.02 * rs.randn(t.size)
+    right = 0.25 * np.sin(2 * np.pi * 1800 * t) + 0.02 * rs.randn(t.size)
+    cases["stereo44k"] = (44100, (np.stack([left, right], 1) * 32767).astype(np.int16))
+    t = np.arange(3 * 8000) / 8000
+    cases["mono8k"] = (8000, (0.4 * np.sin(2 * np.pi * 440 * t) * 32767).astype(np.int16))
+    for name, (sr, wav) in cases.items():
+        path = str(tmp_path / (name + ".wav"))
+        wavfile.write(path, sr, wav)
+        # the reference chain on the CPU: float / 32768 -> to_mono -> librosa.resample -> crop / pad -> TRANSFORMS_16000
+        x = M.to_float_mono(wav)
+        x = R.librosa_resample(x, sr, 16000)
+        want = M.transforms_16000(M.fit_clip(x))
+        got = inp.gen_mel(path)
+        assert got.shape == want.shape and got.shape[0] == 80, (name, got.shape, want.shape)
+        l1, mx = float(np.abs(got - want).mean()), float(np.abs(got - want).max())
+        record(f"tools_Inpaint.gen_mel_{name}", mel_l1=l1, mel_max=mx, tol=1e-5)
+        assert l1 <= 1e-5 and mx <= 2e-4, (name, l1, mx)
+        assert np.array_equal(inp.gen_mel_audio((sr, wav)), got)                         # the Gradio form of the same call
+        out = inp.show_mel_fn(path)
+        assert re.fullmatch(r"image/[0-9a-f]{8}\.png", out), out
+        img = np.array(Image.open(str(tmp_path / out)))
+        ref = (matplotlib.cm.viridis(want[:, :500]) * 255).astype(np.uint8)
+        assert img.shape == ref.shape == (80, 500, 4) and img.dtype == np.uint8
+        # (a 1e-6 mel difference can move a pixel to the neighbouring entry of viridis' 256-entry table: <= 3 / 255 per channel)
+        assert np.abs(img.astype(int) - ref.astype(int)).max() <= 3 and (img != ref).mean() < 2e-3, name
+
+
 # ------------------------------------------------------------------------------------------------ vocoder wrappers
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_vocoder_wrappers_match_reference(golden, precision):

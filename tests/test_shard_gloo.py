@@ -193,3 +193,27 @@ def test_bench_main_multi_rank_control_flow(tmp_path, inflight):
     assert d["last_gather_shape"] == [16, 64]                     # rank 0 ends up with both ranks' waveforms
     assert set(d["comm_ms_per_step"]) == {"C1_broadcast", "C2_gather"}
     assert "roofline" not in d and "cpu_baseline" not in d         # N > 1 lines carry neither (and the stub measures nothing)
+
+
+def test_bench_py_starts_its_own_ranks_when_run_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2 ...` typed as is (no torchrun around it, WORLD_SIZE unset): bench.py re-runs itself as two ranks
+    under torch.distributed.run on 127.0.0.1 and rank 0 prints the ONE JSON line of the whole job (the driver's
+    N = 8 run must not die on a launcher assumption)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-cpu"],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    assert d["ranks_seen"]["n_distinct"] == 2 and len(d["per_rank_value"]) == 2
+    # a launcher that started the wrong number of ranks is an error message, not an assert
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stub-cpu"], capture_output=True, text=True,
+                       env=env2, cwd=str(tmp_path), timeout=120)
+    assert r.returncode != 0 and "--nproc-per-node == --gpus" in r.stderr
