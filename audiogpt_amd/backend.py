@@ -75,8 +75,9 @@ class Context:
 
     def set_cfg_split(self, mode):
         """Classifier-free guidance inside `ddim_sample`: True -> the two halves of the UNet batch as two lanes (two branches of
-        the captured step graph), False -> one stream, None -> the default policy (two lanes unless MAA_CFG_SPLIT=0).  The
-        results are the same bit for bit."""
+        the captured step graph), False -> one stream, None -> the default policy: two lanes only while this context is the ONLY one
+        on its device (one batch owning the GPU gains 4 %; with several contexts in flight the chip is already full from outside and
+        the extra lanes lose up to 24 %).  The results are the same bit for bit."""
         L.check(self.lib.maa_ctx_set_cfg_split(self.h, -1 if mode is None else int(bool(mode))))
 
     def synchronize(self):

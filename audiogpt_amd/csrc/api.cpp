@@ -132,6 +132,7 @@ int maa_ctx_create(int device_id, void* hip_stream, maa_ctx** out) {
             delete c;
             throw;
         }
+        maa::count_context(device_id, +1);
         *out = c;
     });
 }
@@ -143,6 +144,7 @@ int maa_ctx_destroy(maa_ctx* ctx) {
         if (ctx->owns_stream) (void)hipStreamDestroy(ctx->c.stream);
         if (ctx->c.zeros) (void)hipFree(ctx->c.zeros);
         delete ctx->c.prof;
+        maa::count_context(ctx->c.device, -1);
         delete ctx;
     });
 }

@@ -407,7 +407,7 @@ bool launch_flash_attention(const Ctx& ctx, const float* q, int ldq, int hsq, co
     a.o_bs = (long long)Nq * ldo;
     a.zeros = ctx.zeros;
     a.qtiles = (Nq + 127) / 128;
-    a.xcd_on = ctx.tune.xcd_align ? 1 : 0;
+    a.xcd_on = 1;
     const double flops = 4.0 * B * heads * (double)Nq * Nk * dh;
     const double bytes = 4.0 * B * heads * ((double)2 * Nq * dh + 2.0 * Nk * dh);
     ProfScope prof(ctx, "flash_attention", flops, bytes);

@@ -506,7 +506,7 @@ void launch_c(const Ctx& ctx, const HaloArgs& a) {
 // uses the generic implicit GEMM.  MAA_NO_HALO=1 disables it (A/B, bit-identity tests).
 bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, const PackedW& w, int k, int dil, float slope,
                         const float* res, float out_scale, int accumulate, float* out) {
-    const bool off = ctx.tune.no_halo;
+    const bool off = ctx.tune.halo == 0;
     // (C = 128 was tried with a 128-position tile, one workgroup per CU: 72.3 ms vs 70.6 ms for the generic engine on the
     //  config-3 stage -- at that width the layer is MFMA-bound and gains nothing from the staging; not kept)
     if (off || ctx.dtype != 1 || !(C == 32 || C == 64) || w.N != C || w.K != k * C || !w.split || !w.nk) return false;
@@ -554,7 +554,7 @@ bool launch_halo_conv1d(const Ctx& ctx, const float* x, int B, int L, int C, con
 bool launch_halo_pair(const Ctx& ctx, const float* x, int B, int L, int C, const PackedW& w1, int k1, int d1, float slope1,
                       const PackedW& w2, int k2, int d2, float slope2, const float* res, float out_scale, int accumulate,
                       float* out) {
-    if (ctx.tune.no_halo || ctx.tune.no_pair || ctx.dtype != 1 || !(C == 32 || C == 64)) return false;
+    if (ctx.tune.halo != 2 || ctx.dtype != 1 || !(C == 32 || C == 64)) return false;
     for (const PackedW* w : {&w1, &w2})
         if (w->N != C || !w->split || !w->nk) return false;
     if (w1.K != k1 * C || w2.K != k2 * C) return false;

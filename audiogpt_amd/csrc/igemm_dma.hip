@@ -282,12 +282,11 @@ void launch_igemm_dma(const Ctx& ctx, const IGemm& p, int cfg, int Nb) {
     int ns = cfg == 2 ? 2 : cfg == 1 ? 3 : 2;
     // Round 4: a 64x64 launch that puts fewer than ~2.5 workgroups on a CU (the K = 640 linears of the 5 x 39 level: 490 tiles
     // of 20 chunks) has one 16 KB chunk in flight per workgroup and waits ~1 us for each -- latency-, not fill-bound; such
-    // launches take a deeper queue (three stages; MAA_DMA_NS_LOW overrides, 2 = as the others): one batch in flight 842.4 /
-    // 842.2 / 844.6 ms with two stages everywhere against 839.1 (four) / 838.8 (three) in the same call
-    // (profiles/r4_rowchain_ab_v1_serial_loop.txt).
-    if (cfg == 2 && ctx.tune.dma_ns_low > 2) {
+    // launches take a deeper queue (three stages): one batch in flight 842.4 / 842.2 / 844.6 ms with two stages everywhere
+    // against 839.1 (four) / 838.8 (three) in the same call (profiles/r4/r4_rowchain_ab_v1_serial_loop.txt).
+    if (cfg == 2) {
         const long long tiles = (long long)((p.M + 63) / 64) * ((ncols + 63) / 64);
-        if (tiles * 2 < 5LL * device_cu_count(ctx.device)) ns = ctx.tune.dma_ns_low;
+        if (tiles * 2 < 5LL * device_cu_count(ctx.device)) ns = 3;
     }
     switch (cfg) {
         case 0:

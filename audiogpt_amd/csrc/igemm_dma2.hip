@@ -409,7 +409,7 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, int S, float* part) {
     static_assert(lds <= 163840, "LDS per workgroup");
     const long long items = (long long)tiles * S;
     long long grid = items;
-    if (ctx.tune.dma2_persist) {
+    {
         const int per_cu = (int)(163840 / lds) < 32 / NW ? (int)(163840 / lds) : 32 / NW;      // LDS- and wave-limited residency
         const long long cap = (long long)cu_count(ctx) * (per_cu < 1 ? 1 : per_cu);
         if (grid > cap) grid = cap;
@@ -440,18 +440,12 @@ int fit_slices(int nchunks, int S) {
 
 // Which problems take this engine and with how many K slices: a function of the layer (K, packed N) only.
 // MAA_DMA2 = "off" | "0,4,1,S[,kmin[,kmax]]" (tile, stages, pipelining -- one instantiation is kept -- and K slices) overrides
-// the policy for kmin <= K <= kmax; MAA_DMA2_N<packed N> does so for the layers of that width (tuning and tests; parsed when
-// the context is created).
+// the policy for kmin <= K <= kmax (tests; parsed when the context is created).
 Dma2Plan plan_impl(const Ctx& ctx, const IGemm& p) {
     Dma2Plan pl;
     const int ncols = p.N * (p.geglu ? 2 : 1);
     const int nchunks = p.K / BK;
-    const std::string* env = nullptr;
-    auto it = ctx.tune.dma2_n.find(ncols);
-    if (it != ctx.tune.dma2_n.end() && !it->second.empty())
-        env = &it->second;
-    else if (!ctx.tune.dma2.empty())
-        env = &ctx.tune.dma2;
+    const std::string* env = ctx.tune.dma2.empty() ? nullptr : &ctx.tune.dma2;
     if (env) {
         if (*env == "off") return pl;
         int cfg = 0, ns = 4, pipe = 1, S = 1, kmin = 0, kmax = 1 << 30;
@@ -480,12 +474,12 @@ void launch_splitk_reduce(const Ctx& ctx, const IGemm& p, const float* part, int
                           int BN, int WGN, int MI, int NI, int NTH) {
     if (p.geglu && NI % 2 == 0) {
         hipLaunchKernelGGL(splitk_reduce_kernel<2>, dim3((unsigned)(tiles * MI * (NI / 2))), dim3(NTH), 0, ctx.stream, p, part, S,
-                           tiles, ntiles, Nb, BM, BN, WGN, MI, NI, ctx.tune.xcd_align ? 1 : 0);
+                           tiles, ntiles, Nb, BM, BN, WGN, MI, NI, 1);
         return;
     }
     MAA_CHECK(!p.geglu, "split-K reduce: GEGLU needs value / gate block pairs inside a wave");
     hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)(tiles * MI * NI)), dim3(NTH), 0, ctx.stream, p, part, S, tiles,
-                       ntiles, Nb, BM, BN, WGN, MI, NI, ctx.tune.xcd_align ? 1 : 0);
+                       ntiles, Nb, BM, BN, WGN, MI, NI, 1);
 }
 
 Dma2Plan igemm_dma2_plan(const Ctx& ctx, const IGemm& p) { return plan_impl(ctx, p); }

@@ -459,12 +459,6 @@ int pp_ring_lines(const PPGeom& g, int bn) {
 
 template <int MI, int NI, int GWM, int GWN, int NPA, int TERMS>
 void launch_npa_terms(const Ctx& ctx, const IGemm& p, const PPArgs& q, int items, size_t lds) {
-    if (TERMS == 3 && ctx.tune.pp_dbg >= 0) {      // timing ablations (MAA_PP_DBG): a separate instantiation, never the product's
-        auto kern = igemm_pp_kernel<MI, NI, GWM, GWN, NPA, true, true, 0, 3>;
-        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
-        hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
-        return;
-    }
     auto go = [&](auto kern) {
         ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
         hipLaunchKernelGGL(kern, dim3((unsigned)items), dim3(512), lds, ctx.stream, p, q);
@@ -513,16 +507,19 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     q.S = pl.S;
     // slice-major items (rounds 3 - 4, again since round 6): an XCD's contiguous eighth of the items is part of ONE K slice, so its
     // L2 streams 1 / S of the packed weights; tile-major (round 5's default) gave it a few tiles with ALL their slices and every L2
-    // streamed the whole weight tensor: FETCH_SIZE x 3.4 at the 5 x 39 level for the same run time (profiles/r5_bf16x3_pmc_fetch_write.txt)
+    // streamed the whole weight tensor: FETCH_SIZE x 3.4 at the 5 x 39 level for the same run time (profiles/r5/r5_bf16x3_pmc_fetch_write.txt)
     q.tile_major = ctx.tune.pp_tile_major && pl.S > 1 ? 1 : 0;
-    q.dbg = ctx.tune.pp_dbg >= 0 ? ctx.tune.pp_dbg : 0;
+    q.dbg = 0;
     MAA_CHECK((q.nci + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
     MAA_CHECK(q.CAPl > 0, "igemm_pp: the A ring does not fit beside the weight ring");
     const size_t lds = (size_t)q.CAPl * 128 + (size_t)NSB * BN * 128 + 128 + 1024;
     MAA_CHECK(lds <= 163840, "igemm_pp: LDS per workgroup");
     q.items = q.tiles * pl.S;
     const int cus = device_cu_count(ctx.device);
-    const int grid = q.items < cus ? q.items : cus;          // persistent: one workgroup per CU holds the LDS
+    // persistent: one workgroup per CU holds the LDS.  (Round 6, profiles/r6_call4_grid_cap_ab.txt: capping the grid at half the
+    // items -- two items per persistent workgroup, the second's first copies under the first's stores, the other CUs left to
+    // the other contexts' kernels -- is 1 % slower with three batches in flight and 9 % slower with one.)
+    const int grid = q.items < cus ? q.items : cus;
     if (g.npa == 1)
         launch_npa<MI, NI, GWM, GWN, 1>(ctx, p, q, grid, lds);
     else

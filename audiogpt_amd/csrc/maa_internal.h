@@ -97,7 +97,9 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n, int on) {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); safe from several launching threads
 void ensure_dynamic_lds(const void* kernel, int device, int bytes);
-int device_cu_count(int device);      // multiProcessorCount, cached per device
+int device_cu_count(int device);
+int live_contexts(int device);         // contexts created through maa_ctx_create and not yet destroyed, per device (runtime.cpp)
+void count_context(int device, int delta);      // multiProcessorCount, cached per device
 
 // grow-only device buffer owned by a context / model (growing synchronises the stream first: never inside a capture)
 struct DevSlab {
@@ -127,22 +129,14 @@ struct StepGraph {
 // Test / A-B switches: every one of them is parsed in Tuning::load (runtime.cpp) -- the only place the library reads the
 // environment -- when a context is created and again by maa_ctx_reload_tuning; a kept DDIM graph is dropped on reload.
 struct Tuning {
-    std::string dma2;                       // MAA_DMA2 = "off" | "ns,pipe,S[,kmin[,kmax]]"
-    std::map<int, std::string> dma2_n;      // MAA_DMA2_N<packed N>
-    bool dma2_persist = true;               // MAA_DMA2_PERSIST=0: one workgroup per work item
-    std::string pp, pp1;                    // MAA_PP / MAA_PP1 = "off" | "bn,S"
+    std::string dma2;                       // MAA_DMA2 = "off" | "0,4,1,S[,kmin[,kmax]]": the split-K LDS-DMA engine's policy override
+    std::string pp, pp1;                    // MAA_PP / MAA_PP1 = "off" | "bn,S": tile width / K slices of the ping-pong engine (3x3 form, 1x1 form)
     int pp_s_narrow = 2, pp_s_wide = 4;     // MAA_PP_S = "a,b": K slices of the ping-pong engine's 3x3 layers with < 4 / >= 4 N tiles (10x78 / 5x39 in the UNet)
     bool pp_tile_major = false;             // MAA_PP_TILE_MAJOR=1: round 5's item order (a tile's K slices are neighbours); 0: slice-major (an XCD streams 1 / S of the weights)
-    int pp_dbg = -1;                        // MAA_PP_DBG: ablation mask of igemm_pp's TUNE instantiation (-1: product kernel)
     bool op_presplit = false;               // MAA_OP_PRESPLIT=1: the maa_op_* test entry points hand activations over as split32
-    int dma_ns_low = 3;                     // MAA_DMA_NS_LOW: LDS stages of a 64x64 LDS-DMA launch with < 2.5 workgroups per CU (2: as the others)
     bool no_dma = false;                    // MAA_NO_DMA: every bf16 contraction on the register-staged engine (bit-identity tests)
-    bool no_pair = false;                   // MAA_NO_PAIR: the MRF pairs of the narrow vocoder stages as two launches (rounds 2-4; A/B, bit-identity test)
-    bool no_halo = false;                   // MAA_NO_HALO: the narrow vocoder stages through the implicit GEMM (bit-identity test)
-    bool snake_untiled = false;             // MAA_SNAKE_UNTILED: BigVGAN's Activation1d through the untiled kernel (bit-identity test)
-    bool xcd_align = true;                  // MAA_XCD_ALIGN=0: normalisation / attention / reduce workgroups in plain blockIdx order (A/B of xcd_contiguous)
-    bool gn_two_pass = false;               // MAA_GN_TWO_PASS=1: GroupNorm as the statistics + apply launches of rounds 1-4 everywhere (A/B, tests)
-    bool cfg_split = true;                  // MAA_CFG_SPLIT=0: the two halves of a classifier-free-guidance step one after the other on one stream
+    int halo = 2;                           // MAA_HALO = "off": the narrow vocoder stages through the implicit GEMM; "single": their MRF pairs as two halo launches; default: fused pairs (bit-identity tests)
+    bool gn_two_pass = false;               // MAA_GN_TWO_PASS=1: GroupNorm as the statistics + apply launches everywhere (the VAE's large images always take them; tests)
     void load();
 };
 
@@ -157,8 +151,8 @@ struct Ctx {
     // step graph.  Created on first use (side_lane), owned by this context; shares the zero page, the device and the tuning.
     Ctx* side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int cfg_split = -1;       // -1: tune.cfg_split decides; 0 / 1: maa_ctx_set_cfg_split
-    bool split_cfg() const { return cfg_split < 0 ? tune.cfg_split : cfg_split != 0; }
+    int cfg_split = -1;       // -1: two lanes only while this is the device's ONLY context (live_contexts); 0 / 1: maa_ctx_set_cfg_split
+    bool split_cfg() const { return cfg_split < 0 ? live_contexts(device) <= 1 : cfg_split != 0; }
     Tuning tune;
     StepGraph ddim_graph;
     DevSlab sampler_scratch;  // DDIM loop state (tables, step slots, UNet input, eps): reused by every sample() call

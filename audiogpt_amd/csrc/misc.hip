@@ -410,8 +410,7 @@ void launch_snake_aa(const Ctx& ctx, const float* x, int B, int L, int C, const 
         kaiser_sinc_filter12(f);
         MAA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_fir12), f, sizeof(f)));
     });
-    const bool untiled = ctx.tune.snake_untiled;      // bit-identity test of the tiled kernel
-    if (!untiled && (C % 64 == 0 || C == 32) && B <= 65535) {
+    if ((C % 64 == 0 || C == 32) && B <= 65535) {
         ProfScope prof(ctx, "snake_aa_kernel", 0.0, 8.0 * (double)B * L * C);
         const dim3 grid((unsigned)((L + 63) / 64), (unsigned)(C % 64 == 0 ? C / 64 : 1), (unsigned)B);
         if (C % 64 == 0)

@@ -483,7 +483,7 @@ void launch_groupnorm(Ctx& ctx, const float* x1, int ld1, int C1, const float* x
         dim3 grid((unsigned)(nblk * B));
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, grid, dim3((unsigned)fp.threads), fp.lds, ctx.stream, x1, ld1, C1, x2, ld2, C2, HW, groups, fp.gpb, eps,
-                               gamma, beta, silu, out, out_split, raw_split, nblk, ctx.tune.xcd_align ? 1 : 0);
+                               gamma, beta, silu, out, out_split, raw_split, nblk, 1);
         };
         switch (fp.nr) {
             case 1: go(gn_fused_kernel<1>); break;
@@ -512,7 +512,7 @@ void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, con
     MAA_CHECK(C <= 2048 && C % 4 == 0, "layernorm width");
     ProfScope prof(ctx, "layernorm", 0.0, 8.0 * rows * (double)C);
     dim3 grid((unsigned)((rows + 3) / 4));
-    const int xa = ctx.tune.xcd_align ? 1 : 0;
+    const int xa = 1;
     if (C <= 256)
         hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, ctx.stream, x, rows, C, gamma, beta, eps, out, out_split, xa);
     else if (C <= 512)

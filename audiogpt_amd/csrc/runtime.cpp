@@ -8,6 +8,7 @@
 
 #include <mutex>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -158,13 +159,6 @@ void Tuning::load() {
     dma2 = get_s("MAA_DMA2");
     pp = get_s("MAA_PP");
     pp1 = get_s("MAA_PP1");
-    dma2_n.clear();
-    for (char** e = ::environ; e && *e; ++e) {
-        int n = 0, used = 0;
-        if (std::sscanf(*e, "MAA_DMA2_N%d=%n", &n, &used) == 1 && used > 0) dma2_n[n] = *e + used;
-    }
-    const std::string pe = get_s("MAA_DMA2_PERSIST");
-    dma2_persist = pe.empty() || pe[0] != '0';
     pp_s_narrow = 2;
     pp_s_wide = 4;
     const std::string pss = get_s("MAA_PP_S");
@@ -172,39 +166,24 @@ void Tuning::load() {
     if (pp_s_narrow < 1) pp_s_narrow = 1;
     if (pp_s_wide < 1) pp_s_wide = 1;
     pp_tile_major = get_s("MAA_PP_TILE_MAJOR") == "1";
-    const std::string pd = get_s("MAA_PP_DBG");
-    pp_dbg = pd.empty() ? -1 : std::atoi(pd.c_str());
     const std::string ps = get_s("MAA_OP_PRESPLIT");
     op_presplit = !ps.empty() && ps[0] == '1';
-    const std::string nl = get_s("MAA_DMA_NS_LOW");
-    dma_ns_low = nl.empty() ? 3 : std::atoi(nl.c_str());
     no_dma = !get_s("MAA_NO_DMA").empty();
-    no_halo = !get_s("MAA_NO_HALO").empty();
-    snake_untiled = !get_s("MAA_SNAKE_UNTILED").empty();
+    const std::string hs = get_s("MAA_HALO");
+    halo = hs == "off" ? 0 : hs == "single" ? 1 : 2;
     gn_two_pass = get_s("MAA_GN_TWO_PASS") == "1";
-    xcd_align = get_s("MAA_XCD_ALIGN") != "0";
-    no_pair = get_s("MAA_NO_PAIR") == "1";
-    const std::string cs = get_s("MAA_CFG_SPLIT");
-    cfg_split = cs.empty() || cs[0] != '0';
     // a stale override in an older round's format ("2,2,0,1": tile, stages ...) is refused here, when the context is created
     // (last, so that every other knob is in place), not by a check in the middle of a forward pass
-    std::string first_error;
-    auto check_dma2 = [&first_error](const std::string& name, std::string& v) {
-        if (v.empty() || v == "off") return;
+    if (!dma2.empty() && dma2 != "off") {
         int cfg = 0, ns = 4, pipe = 1, S = 1, kmin = 0, kmax = 0;
-        const int k = std::sscanf(v.c_str(), "%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &kmax);
+        const int k = std::sscanf(dma2.c_str(), "%d,%d,%d,%d,%d,%d", &cfg, &ns, &pipe, &S, &kmin, &kmax);
         if (k < 4 || cfg != 0 || ns != 4 || pipe != 1 || S < 1) {
-            const std::string bad = v;
-            v.clear();      // the context keeps running on the default policy if the caller catches the error
-            if (first_error.empty())
-                first_error = name + "=\"" + bad + "\": expected \"off\" or \"0,4,1,S[,kmin[,kmax]]\" (the split-K engine keeps one "
-                              "instantiation: tile 0, 4 stages, pipelined; S = K slices)";
+            const std::string bad = dma2;
+            dma2.clear();      // the context keeps running on the default policy if the caller catches the error
+            throw Error("MAA_DMA2=\"" + bad + "\": expected \"off\" or \"0,4,1,S[,kmin[,kmax]]\" (the split-K engine keeps one "
+                        "instantiation: tile 0, 4 stages, pipelined; S = K slices)");
         }
-    };
-    // every override is validated (and a bad one cleared) before the first error is reported: no stale value survives a caught error
-    check_dma2("MAA_DMA2", dma2);
-    for (auto& kv : dma2_n) check_dma2("MAA_DMA2_N" + std::to_string(kv.first), kv.second);
-    if (!first_error.empty()) throw Error(first_error);
+    }
 }
 
 Ctx::~Ctx() {
@@ -257,6 +236,14 @@ void ensure_dynamic_lds(const void* kernel, int device, int bytes) {
     if (have >= bytes) return;
     MAA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     have = bytes;
+}
+
+namespace {
+std::atomic<int> g_live_contexts[64];
+}
+int live_contexts(int device) { return device >= 0 && device < 64 ? g_live_contexts[device].load() : 1; }
+void count_context(int device, int delta) {
+    if (device >= 0 && device < 64) g_live_contexts[device].fetch_add(delta);
 }
 
 int device_cu_count(int device) {

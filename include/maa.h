@@ -63,14 +63,14 @@ int maa_ctx_set_precision(maa_ctx* ctx, int mode);
  * unconditional and the conditional half of that batch are independent trajectories until the combine, and the library runs
  * them as two lanes -- two branches of the captured step graph, each half on its own stream and workspace -- because one batch
  * of 8 prompts leaves much of the chip idle.  Bit-identical to the one-stream form (every kernel is batch-invariant).
- *   1 two lanes, 0 one stream, -1 the default policy (two lanes unless MAA_CFG_SPLIT=0).
- * A server that already keeps several independent batches in flight on several contexts may prefer 0. */
+ *   1 two lanes, 0 one stream, -1 the default policy: two lanes only while this is the device's ONLY live context (measured:
+ * +4 % for one batch owning the GPU, -24 % with three contexts' batches in flight, profiles/r5/r5_call1_cfg_lanes_ab.txt) -- a
+ * server that keeps several batches in flight on several contexts gets one stream per context without asking. */
 int maa_ctx_set_cfg_split(maa_ctx* ctx, int mode);
-/* The tuning / test knobs of the environment (MAA_PP, MAA_PP1, MAA_DMA2, MAA_DMA2_N<n>, MAA_DMA2_PERSIST, MAA_PP_DBG,
- * MAA_OP_PRESPLIT, MAA_DMA_NS_LOW, MAA_NO_DMA, MAA_NO_HALO, MAA_SNAKE_UNTILED, MAA_CFG_SPLIT) are
- * parsed in one place, when a context is created; this parses them again (and drops the step graph the sampler keeps).  A
- * malformed MAA_DMA2 / MAA_DMA2_N<n> value fails here (and in maa_ctx_create) with a message naming the variable.  For tests
- * and A/B runs. */
+/* The test / A-B knobs of the environment (MAA_PP, MAA_PP1, MAA_PP_S, MAA_PP_TILE_MAJOR, MAA_DMA2, MAA_NO_DMA, MAA_HALO,
+ * MAA_OP_PRESPLIT, MAA_GN_TWO_PASS) are parsed in one place, when a context is created; this parses them again
+ * (and drops the step graph the sampler keeps).  A malformed MAA_DMA2 value fails here (and in maa_ctx_create) with a message
+ * naming the variable.  For tests and A/B runs; a -DMAA_NO_TUNING build ignores the environment. */
 int maa_ctx_reload_tuning(maa_ctx* ctx);
 /* bytes currently reserved for the activation workspace, the second CFG lane's arena included (it exists once a guided sample()
  * has run with two lanes and is kept for the context's lifetime) */

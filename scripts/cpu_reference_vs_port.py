@@ -7,7 +7,7 @@ seeded weights loaded strict, tests/golden/make_golden.py's recipe) and through 
 reference (what a `kind: "port"` number has to be multiplied by to read as a `kind: "reference"` one) and the max-abs difference of the
 two waveforms.  Test / measurement infrastructure only: nothing under audiogpt_amd/ imports it.
 
-    python scripts/cpu_reference_vs_port.py [ddim steps, default 10] > profiles/r5_cpu_reference_vs_port.txt
+    python scripts/cpu_reference_vs_port.py [ddim steps, default 10] > profiles/r5/r5_cpu_reference_vs_port.txt
 """
 import os
 import sys

@@ -151,20 +151,15 @@ def test_split_k_is_deterministic_and_batch_invariant(ctx, variant):
 def test_persistent_workgroups_match_one_workgroup_per_item(ctx, variant):
     """A grid smaller than the number of (slice, tile) items: every workgroup runs several items as one stream of K
     chunks (the next item's copies are issued before this item's epilogue).  Batch 16 of the benchmark's 10x78 level has
-    975 64x64 tiles -- several per workgroup; the result must be bit-identical to one workgroup per item."""
+    975 64x64 tiles -- several per workgroup; a sample's rows must be bit-identical to a launch small enough for one item per
+    workgroup."""
     x = torch.randn(16, 320, 10, 78, generator=g(41))
     w = torch.randn(320, 320, 3, 3, generator=g(42)) / math.sqrt(2880)
     b = torch.randn(320, generator=g(43))
     with forced(variant):
         y = ctx.op_conv(x, w, b, pad=1).cpu()
-        os.environ["MAA_DMA2_PERSIST"] = "0"
-        ctx.reload_tuning()
-        try:
-            y1 = ctx.op_conv(x, w, b, pad=1).cpu()
-        finally:
-            os.environ.pop("MAA_DMA2_PERSIST", None)
-            ctx.reload_tuning()
-    assert torch.equal(y, y1)
+        y1 = ctx.op_conv(x[:2], w, b, pad=1).cpu()      # 2 samples: fewer items than workgroup slots, one item per workgroup
+    assert torch.equal(y[:2], y1)
     check(f"dma2[{variant}]_persistent_conv_b16", y, F.conv2d(x, w, b, padding=1), TOL)
     a = torch.randn(12480, 320, generator=g(44))
     wl = torch.randn(960, 320, generator=g(45)) / math.sqrt(320)

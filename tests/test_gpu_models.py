@@ -254,11 +254,10 @@ def test_cfg_halves_as_two_lanes_are_bit_identical_to_one_stream(golden, precisi
 
 
 
-def test_xcd_contiguous_work_order_does_not_change_results(golden):
-    """Round 5: the workgroups of the one-pass GroupNorm, LayerNorm, flash attention and the split-K reduce take their work items in
-    XCD-contiguous order (a sample's rows are read and written on the XCD whose igemm tiles produce / consume them) and the K
-    slices of a convolution tile are neighbours in the item order.  Scheduling only: the UNet's output equals the MAA_XCD_ALIGN=0
-    form bit for bit."""
+def test_conv_item_order_does_not_change_results(golden):
+    """The (K slice, tile) work items of a split-K convolution launch are walked slice-major (default since round 6: an XCD's
+    contiguous eighth of the items belongs to one K slice, so its L2 streams 1 / S of the packed weights) or tile-major (round
+    5, MAA_PP_TILE_MAJOR=1).  Scheduling only: the UNet's output is the same bit for bit."""
     import os
     from audiogpt_amd.backend import Context, UNet, reload_tuning
     g = golden("unet_t2a")
@@ -269,13 +268,13 @@ def test_xcd_contiguous_work_order_does_not_change_results(golden):
     out = {}
     try:
         for mode in ("0", "1"):
-            os.environ["MAA_XCD_ALIGN"] = mode
+            os.environ["MAA_PP_TILE_MAJOR"] = mode
             reload_tuning()
             out[mode] = u(x, t, c).cpu()
     finally:
-        os.environ.pop("MAA_XCD_ALIGN", None)
+        os.environ.pop("MAA_PP_TILE_MAJOR", None)
         reload_tuning()
     assert torch.equal(out["0"], out["1"])
-    check("unet_t2a_xcd_aligned_vs_reference", out["1"][:g["y"].shape[0]], g["y"], 2e-4)
+    check("unet_t2a_slice_major_vs_reference", out["0"][:g["y"].shape[0]], g["y"], 2e-4)
     u.close()
     ctx.close()

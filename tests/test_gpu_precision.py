@@ -340,7 +340,7 @@ np.savez({out!r}, **outs)
 
 def test_halo_conv1d_bit_identical_to_the_implicit_gemm(tmp_path):
     """The narrow vocoder stages (C = 32 / 64) run through halo_conv1d.hip (input tile staged once in LDS for all taps);
-    MAA_NO_HALO=1 sends them through the generic implicit GEMM.  Same products in the same order per accumulator: whole
+    MAA_HALO=off sends them through the generic implicit GEMM.  Same products in the same order per accumulator: whole
     generator passes (HiFi-GAN uic 512 / 128, BigVGAN; ragged lengths, tail tiles, every kernel size and dilation) agree
     bit for bit."""
     import os
@@ -350,16 +350,12 @@ def test_halo_conv1d_bit_identical_to_the_implicit_gemm(tmp_path):
     import numpy as np
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    # (third run: BigVGAN's Activation1d through the per-element kernel instead of the tiled one -- same arithmetic and order)
-    # (fourth run: the MRF pairs of the narrow HiFi-GAN stages as two halo launches instead of the fused pair kernel of round 5,
+    # (third run: the MRF pairs of the narrow HiFi-GAN stages as two halo launches instead of the fused pair kernel of round 5,
     # which is what the first run takes -- the intermediate tensor through LDS instead of through memory, same arithmetic)
-    for tag, env in (("halo", {}), ("igemm", {"MAA_NO_HALO": "1"}), ("snake_untiled", {"MAA_SNAKE_UNTILED": "1"}),
-                     ("two_launches", {"MAA_NO_PAIR": "1"})):
+    for tag, env in (("halo", {}), ("igemm", {"MAA_HALO": "off"}), ("two_launches", {"MAA_HALO": "single"})):
         out = str(tmp_path / f"v_{tag}.npz")
         e = dict(os.environ)
-        e.pop("MAA_NO_HALO", None)
-        e.pop("MAA_NO_PAIR", None)
-        e.pop("MAA_SNAKE_UNTILED", None)
+        e.pop("MAA_HALO", None)
         e.update(env)
         r = subprocess.run([sys.executable, "-c", _HALO_SCRIPT.format(root=root, out=out)], env=e, capture_output=True,
                            text=True, timeout=600)
@@ -373,7 +369,7 @@ def test_halo_conv1d_bit_identical_to_the_implicit_gemm(tmp_path):
 
 def test_fused_mrf_pair_is_taken_and_equals_the_two_launches(ctx3):
     """halo_pair_kernel (c1 -> leaky -> c2 -> + x in one launch, xt kept in LDS) runs the narrow stages of the HiFi-GAN generators
-    by default; MAA_NO_PAIR=1 restores the two launches per pair.  Lengths that put a sample boundary, a one-row tail tile and
+    by default; MAA_HALO=single restores the two launches per pair.  Lengths that put a sample boundary, a one-row tail tile and
     several tiles per sample (246 / 118 output rows per tile at k = 11) into play; bit-identical waveforms."""
     from audiogpt_amd.backend import Vocoder
     gen = torch.Generator().manual_seed(11)
@@ -384,7 +380,7 @@ def test_fused_mrf_pair_is_taken_and_equals_the_two_launches(ctx3):
         y = v(mel).cpu()
         rows = ctx3.prof_end()
         assert any(k.startswith("halo_pair_bf16x3") for k in rows), rows.keys()
-        with _env(MAA_NO_PAIR="1"):
+        with _env(MAA_HALO="single"):
             ctx3.prof_begin()
             y2 = v(mel).cpu()
             rows2 = ctx3.prof_end()

@@ -532,17 +532,17 @@ def test_committed_traffic_table_carries_the_headlines_launch_mix(tmp_path):
 
 
 def test_round5_record_slims_to_the_committed_line():
-    """The full record of the round-5 validation run (profiles/r5_bf16x3_bench_detail.json) -> the stdout line: within the limit,
+    """The full record of the round-5 validation run (profiles/r5/r5_bf16x3_bench_detail.json) -> the stdout line: within the limit,
     the literal configs[1] number (one batch owning the GPU, both CFG forms, bit-identical), box.class and every secondary value."""
     import json
     import sys
     sys.path.insert(0, ROOT)
     import bench
-    full = json.load(open(os.path.join(ROOT, "profiles", "r5_bf16x3_bench_detail.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r5", "r5_bf16x3_bench_detail.json")))
     line = bench.slim_line(full, "gpurun_out/bench_detail.json")
     assert len(line) <= bench.LINE_LIMIT
     d = json.loads(line)
-    shipped = json.load(open(os.path.join(ROOT, "profiles", "r5_bf16x3_bench.json")))
+    shipped = json.load(open(os.path.join(ROOT, "profiles", "r5", "r5_bf16x3_bench.json")))
     assert d["value"] == shipped["value"] and d["one_batch_in_flight"] == shipped["one_batch_in_flight"]
     assert d["one_batch_in_flight"]["cfg_lanes"] == 2 and d["one_batch_other_form"]["cfg_lanes"] == 1 and d["one_batch_other_form"]["bit_identical"] is True
     assert d["box"]["class"] == "fast" and d["config"]["cfg_lanes"] == 1 and d["config"]["batches_in_flight"] == 3

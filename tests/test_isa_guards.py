@@ -95,7 +95,7 @@ def test_no_scratch_inside_any_mfma_loop(asm):
             if not any("v_mfma" in l for l in body):
                 continue
             if f == "igemm_pp.hip" and _pp_tune_build(name):
-                continue      # TUNE = true: the ablation build (MAA_PP_DBG), timing only, never selected by default
+                continue      # TUNE = true: the ablation build of rounds 3 - 5 (no longer instantiated)
             if f == "igemm_f32.hip" and "ILi128ELi128ELi2ELi2ELb0E" in name:
                 # KNOWN, exact-fp32 mode only: the unaligned-operand path of the 128x128 tile indexes its staging registers
                 # at run time, which puts them in an 80-byte stack slot (8 scratch instructions per 64 MFMAs).  Not on the
