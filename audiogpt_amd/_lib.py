@@ -93,7 +93,7 @@ class maa_plms_args(C.Structure):
 
 EXPORTS = [
     "maa_last_error", "maa_version", "maa_ctx_create", "maa_ctx_destroy", "maa_ctx_synchronize",
-    "maa_ctx_set_stream", "maa_ctx_set_precision", "maa_ctx_set_cfg_split", "maa_ctx_reload_tuning", "maa_ctx_workspace_bytes", "maa_prof_begin", "maa_prof_end", "maa_unet_create", "maa_unet_destroy",
+    "maa_ctx_set_stream", "maa_ctx_set_precision", "maa_ctx_set_cfg_split", "maa_ctx_set_concurrency", "maa_ctx_reload_tuning", "maa_ctx_workspace_bytes", "maa_prof_begin", "maa_prof_end", "maa_unet_create", "maa_unet_destroy",
     "maa_unet_set_context", "maa_unet_forward", "maa_ddim_update", "maa_ddim_sample", "maa_vae_create",
     "maa_vae_destroy", "maa_vae_decode", "maa_vae_decode_spec", "maa_vae_encode_moments", "maa_vocoder_create", "maa_vocoder_destroy",
     "maa_vocoder_forward", "maa_vocoder_forward_f0", "maa_diffnet_create", "maa_diffnet_destroy", "maa_diffnet_forward",
@@ -129,6 +129,7 @@ def load():
         "maa_ctx_workspace_bytes": [vp, C.POINTER(C.c_size_t)],
         "maa_ctx_set_precision": [vp, ci],
         "maa_ctx_set_cfg_split": [vp, ci],
+        "maa_ctx_set_concurrency": [vp, ci],
         "maa_ctx_reload_tuning": [vp],
         "maa_prof_begin": [vp, ci],
         "maa_prof_end": [vp, C.POINTER(maa_prof_row), ci, C.POINTER(ci)],

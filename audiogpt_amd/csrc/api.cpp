@@ -178,6 +178,15 @@ int maa_ctx_workspace_bytes(maa_ctx* ctx, size_t* out) {
     });
 }
 
+int maa_ctx_set_concurrency(maa_ctx* ctx, int n) {
+    return guarded([&] {
+        bind(ctx);
+        MAA_CHECK(n >= -1 && n != 0, "concurrency: -1 (guess from the live contexts) or the number of contexts kept in flight (>= 1)");
+        if (ctx->c.kept_full() != ((n < 0 ? maa::live_contexts(ctx->c.device) : n) >= 3))
+            ctx->c.ddim_graph.clear();      // the kept step graph was captured under the other arrangement's launches
+        ctx->c.concurrency = n;
+    });
+}
 int maa_ctx_set_cfg_split(maa_ctx* ctx, int mode) {
     return guarded([&] {
         bind(ctx);

@@ -404,7 +404,7 @@ bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms) {
         // 49 workgroups of 90 chunks each).  No K split either way: the two tiles give bit-identical results.
         cfg = (long long)((p.M + 255) / 256) * p.Z < 128 ? 4 : 3;
     } else {
-        cfg = choose_tile(p.M, ncols, p.Z, true);
+        cfg = choose_tile(p.M, ncols, p.Z, true, ctx.kept_full() ? 1 : 0);
     }
     const bool no_dma = ctx.tune.no_dma;      // tests: same arithmetic, register staging
     // both bf16 modes: split32 x split32 problems go to the LDS-DMA engines (TERMS = 1: the hi halves are the bf16 operands)

@@ -151,8 +151,15 @@ struct Ctx {
     // step graph.  Created on first use (side_lane), owned by this context; shares the zero page, the device and the tuning.
     Ctx* side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int cfg_split = -1;       // -1: two lanes only while this is the device's ONLY context (live_contexts); 0 / 1: maa_ctx_set_cfg_split
-    bool split_cfg() const { return cfg_split < 0 ? live_contexts(device) <= 1 : cfg_split != 0; }
+    // How many contexts' launches the caller keeps in flight on this device (maa_ctx_set_concurrency).  >= 3 = the chip is kept
+    // full from outside: a launch then costs the sum of its workgroups' time, not the rounds its own grid makes -- one stream per
+    // guided DDIM step and igemm tiles by least total workgroup time; 1 or 2 = this context (nearly) owns the GPU: two CFG lanes
+    // (+4 % with one context, +3.8 % with two, -24 % with three: profiles/r5/r5_call1_cfg_lanes_ab.txt, r5_call2_mixed_cfg_lanes_ab.txt),
+    // tiles by least launch time; -1 (default): guessed from the number of live contexts.  Every choice here is bit-identical.
+    int concurrency = -1;
+    bool kept_full() const { return (concurrency < 0 ? live_contexts(device) : concurrency) >= 3; }
+    int cfg_split = -1;       // -1: two lanes unless kept_full(); 0 / 1: maa_ctx_set_cfg_split
+    bool split_cfg() const { return cfg_split < 0 ? !kept_full() : cfg_split != 0; }
     Tuning tune;
     StepGraph ddim_graph;
     DevSlab sampler_scratch;  // DDIM loop state (tables, step slots, UNet input, eps): reused by every sample() call
@@ -220,7 +227,7 @@ void launch_igemm(const Ctx& ctx, const IGemm& p);
 // Tile choice shared by the fp32 and bf16 engines: 0 = 128x128, 1 = 128x64, 2 = 64x64 (3 = 256x32 is chosen by
 // the callers for N <= 32).  Cost = CU-rounds x tile area / (tile efficiency x latency hiding at that many
 // co-resident blocks per CU); knobs can be overridden for tuning with MAA_TILE_EFF / MAA_CONC_EFF / MAA_FORCE_CFG.
-int choose_tile(long long M, long long N, int Z, bool bf16);
+int choose_tile(long long M, long long N, int Z, bool bf16, int mode = 0);      // mode 1: least total workgroup time (several contexts keep the chip full)
 bool launch_igemm_bf16(const Ctx& ctx, const IGemm& p, int terms);   // false: not eligible, use the fp32 kernel
 // bf16x3 with LDS-DMA tile copies, both operands split32 (igemm_dma.hip); called by launch_igemm_bf16
 int igemm_dma_tile(const IGemm& p, int cfg);      // tile the DMA engine runs for the generic choice `cfg`

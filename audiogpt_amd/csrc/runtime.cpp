@@ -118,7 +118,7 @@ struct TileKnobs {
     double conc[3] = {0.55, 0.85, 1.00};      // latency hiding with 1 / 2 / >=3 co-resident blocks per CU
 };
 }  // namespace
-int choose_tile(long long M, long long N, int Z, bool bf16) {
+int choose_tile(long long M, long long N, int Z, bool bf16, int mode) {
     static const TileKnobs k;
     static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
     const int max_occ[3] = {bf16 ? 2 : 3, bf16 ? 2 : 4, 4};   // blocks per CU allowed by LDS / registers
@@ -128,7 +128,10 @@ int choose_tile(long long M, long long N, int Z, bool bf16) {
         const long long blocks = ((M + bm[c] - 1) / bm[c]) * ((N + bn[c] - 1) / bn[c]) * Z;
         const long long per_cu = (blocks + 255) / 256;
         const int co = (int)(per_cu < max_occ[c] ? per_cu : max_occ[c]);
-        const double cost = (double)per_cu * bm[c] * bn[c] / (k.eff[c] * k.conc[co >= 3 ? 2 : co - 1]);
+        // mode 1: the chip is kept full from outside (other contexts' launches run on the CUs this one leaves idle), so what a
+        // launch costs is the sum of its workgroups' time, padding included -- not the rounds its own grid makes
+        const double cost = mode == 1 ? (double)blocks * bm[c] * bn[c] / k.eff[c]
+                                      : (double)per_cu * bm[c] * bn[c] / (k.eff[c] * k.conc[co >= 3 ? 2 : co - 1]);
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
@@ -212,6 +215,7 @@ Ctx& side_lane(Ctx& ctx) {
     }
     ctx.side->tune = ctx.tune;
     ctx.side->dtype = ctx.dtype;
+    ctx.side->concurrency = ctx.kept_full() ? 3 : 1;      // the lane follows its context's arrangement (it must not guess on its own)
     return *ctx.side;
 }
 

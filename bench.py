@@ -149,6 +149,10 @@ def main(argv=None):
     ap.add_argument("--force-collectives", action="store_true",
                     help="initialise the process group and issue C1 scatter / broadcast, C2 gather, the barriers and ranks_seen even "
                          "with ONE rank (RCCL exercised on the one GPU a test box has: tests/test_gpu_rccl.py)")
+    ap.add_argument("--concurrency", type=int, default=0,
+                    help="the serving-arrangement hint handed to the library (maa_ctx_set_concurrency); 0 = --inflight.  Profile passes "
+                         "run ONE stream with the headline's launches: --inflight 1 --cfg-split 0 --concurrency 3")
+    ap.add_argument("--no-one-batch", action="store_true", help="skip the `one_batch_in_flight` measurement that follows an overlapped run")
     ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)      # tests: this file's control flow on CPU / gloo
     ap.add_argument("--json-out", default=None, help="also write the FULL record (what gpurun_out/bench_detail.json holds) to this file")
     ap.add_argument("--full-line", action="store_true",
@@ -222,6 +226,7 @@ def main(argv=None):
     lanes_one = args.cfg_split != "0"
     if not stub:
         for p_ in pipes:
+            p_.ctx.set_concurrency(args.concurrency or inflight)      # the serving arrangement as a hint (tiles by total workgroup time when >= 3)
             p_.ctx.set_cfg_split(lanes)
     # worker threads start with torch's thread-local device at 0: pin them to this rank's GPU (no stray context on GPU 0)
     pool = ThreadPoolExecutor(max_workers=inflight) if stub else \
@@ -354,6 +359,7 @@ def main(argv=None):
                    "prompts_per_gpu": n, "ddim_steps": S, "latent": list(LATENT), "mel_frames": CLIP_FRAMES,
                    "audio_seconds_per_step": pipe.audio_seconds(n * world, CLIP_FRAMES), "hipgraph": use_graph,
                    "batches_in_flight": inflight, "cfg_lanes": 2 if lanes else 1,
+                   "concurrency_hint": args.concurrency or inflight,      # maa_ctx_set_concurrency: >= 3 -> short-K tiles by total workgroup time
                    "parallelism": "prompt-sharded x%d (RCCL bcast cond / gather wav)" % world},
         "comm_ms_per_step": {k: round(v, 4) for k, v in comm_ms.items()},
         # Little's law for the overlapped arrangement: `inflight` batches are resident for `inflight` throughput periods
@@ -373,11 +379,18 @@ def main(argv=None):
     if rank == 0 and not args.no_roofline:
         # one more batch, eager (graph launches cannot be event-timed), every kernel bracketed by hipEvents on the
         # library's stream; the dominant kernel family is the implicit-GEMM engine of the precision mode
+        # (ONE stream: a launch's duration only means something with the tiles chosen for a launch alone, so the context is told it
+        # owns the GPU for this pass -- the timed region's replicas take the short-K contractions' tiles by total workgroup time,
+        # maa_ctx_set_concurrency; the convolution engine, the dominant kernel, is the same code in both arrangements)
         c = c_all[:n]
         uc = uc_row.expand(n, -1, -1).contiguous()
+        pipe.ctx.set_concurrency(1)
+        pipe.ctx.set_cfg_split(False)
         pipe.ctx.prof_begin()
         pipe.generate(x_T, c, uc, CFG_SCALE, S, use_graph=False)
         rows = pipe.ctx.prof_end()
+        pipe.ctx.set_concurrency(args.concurrency or inflight)
+        pipe.ctx.set_cfg_split(lanes)
         result["roofline"] = roofline_of(rows, args.precision)
         # HBM-side traffic per launch: measured by scripts/gpu_profile.sh on the GPU box right before this run (separate
         # rocprofv3 PMC passes); accepted only for this binary and launch mix (attach_traffic)
@@ -388,7 +401,7 @@ def main(argv=None):
                     k, v["launches"], v["ms"], v["flops"] / max(v["ms"], 1e-9) / 1e9, v["bytes"] / max(v["ms"], 1e-9) / 1e6))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (bounded sample, ~25 s of host time)
         result["cpu_baseline"] = cpu_baseline()
-    if rank == 0 and world == 1 and inflight > 1 and args.steps >= 2:
+    if rank == 0 and world == 1 and inflight > 1 and args.steps >= 2 and not args.no_one_batch:
         one_batch_records(result, pipe, x_T, c_all, uc_row, n, S, use_graph, lanes, lanes_one, stub, args.steps, barrier)
     if rank == 0 and world == 1 and not args.no_secondary:
         run_secondaries(result, pipes, dev, args)

@@ -183,6 +183,7 @@ def run_t2a_variant(dev, precision, vocoder_cfg, label, cpu_parts=None, steps=6,
     n, S = PROMPTS_PER_GPU, DDIM_STEPS
     pipes = [MakeAnAudio(dev, vocoder_cfg=vocoder_cfg, precision=precision, stream=torch.cuda.Stream(dev)) for _ in range(inflight)]
     for p_ in pipes:
+        p_.ctx.set_concurrency(inflight)
         p_.ctx.set_cfg_split(inflight == 1)      # (as the headline: lanes only when one batch owns the GPU)
     x_T, c, uc = _t2a_inputs(n, dev)
     pool = ThreadPoolExecutor(max_workers=inflight, initializer=torch.cuda.set_device, initargs=(dev,))
@@ -194,9 +195,11 @@ def run_t2a_variant(dev, precision, vocoder_cfg, label, cpu_parts=None, steps=6,
     round_of(inflight)        # warm-up: every replica sizes its workspace and captures its step graph
     per_step, _ = _timed(lambda: round_of(steps), 1)
     per_step /= steps
+    pipes[0].ctx.set_concurrency(1)
     pipes[0].ctx.set_cfg_split(True)
     gen(pipes[0])                                  # (the step graph of the two-lane form)
     one, (wav, spec, z) = _timed(lambda: gen(pipes[0]), 2)
+    pipes[0].ctx.set_concurrency(inflight)
     pipes[0].ctx.set_cfg_split(inflight == 1)
     audio_s = pipes[0].audio_seconds(n, CLIP_FRAMES)
     res = {"metric": "generated audio-seconds/sec (10s clip, 100 DDIM steps) [%d independent batches of %d prompts in flight]" % (inflight, n),
@@ -315,6 +318,7 @@ def one_batch_records(result, pipe, x_T, c_all, uc_row, n, S, use_graph, lanes, 
     # the same K steps strictly one batch after another on one stream (the latency-oriented number)
     k1 = min(steps, 3)
     if not stub:
+        pipe.ctx.set_concurrency(1)      # ONE batch owns the GPU now
         pipe.ctx.set_cfg_split(lanes_one)
         pipe.generate(x_T, c_all[:n], uc_row.expand(n, -1, -1).contiguous(), CFG_SCALE, S, use_graph=use_graph)      # (its step graph)
     barrier()

@@ -254,6 +254,40 @@ def test_cfg_halves_as_two_lanes_are_bit_identical_to_one_stream(golden, precisi
 
 
 
+def test_serving_arrangement_hint_changes_tiles_and_lanes_but_not_results(golden):
+    """maa_ctx_set_concurrency (round 6): told that three contexts are kept in flight, a context takes the short-K contractions'
+    tile by least total workgroup time (128 x 64 / 128 x 128 where a launch alone takes 64 x 64) and runs a guided DDIM step on one
+    stream; told that it owns the GPU, 64 x 64 tiles and two CFG lanes.  No K split is involved: the UNet's output and a guided
+    trajectory are the same bit for bit, a batch of 16 (the benchmark's) and the golden's batch alike."""
+    from audiogpt_amd.backend import Context, UNet
+    g = golden("unet_t2a")
+    x, t, c = torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["context"])
+    reps = -(-16 // x.shape[0])
+    x16, t16, c16 = (torch.cat([v] * reps)[:16] for v in (x, t, c))
+    ctx = Context("cuda:0", precision="bf16x3")
+    u = UNet(ctx, C.UNET_T2A, WT.make_unet_state_dict(C.UNET_T2A, seed=0))
+    gd = golden("ddim_t2a_s10")
+    steps, a, ap = _ddim_tables(4, C.LDM_T2A)
+    kw = dict(cond=torch.from_numpy(gd["c"]), uncond=torch.from_numpy(gd["uc"]), scale=float(gd["scale"]))
+    out, fams, traj = {}, {}, {}
+    try:
+        for n in (1, 3):
+            ctx.set_concurrency(n)
+            ctx.prof_begin()
+            out[n] = u(x16, t16, c16).cpu()
+            fams[n] = {k: v["launches"] for k, v in ctx.prof_end().items() if k.startswith("igemm_dma_bf16x3")}
+            traj[n] = u.ddim_sample(torch.from_numpy(gd["x_T"]), steps, a, ap, use_graph=True, **kw).cpu()
+        ctx.set_concurrency(None)
+    finally:
+        u.close()
+        ctx.close()
+    assert fams[1].get("igemm_dma_bf16x3<64x64>", 0) > fams[3].get("igemm_dma_bf16x3<64x64>", 0), fams
+    assert fams[3].get("igemm_dma_bf16x3<128x64>", 0) + fams[3].get("igemm_dma_bf16x3<128x128>", 0) > \
+        fams[1].get("igemm_dma_bf16x3<128x64>", 0) + fams[1].get("igemm_dma_bf16x3<128x128>", 0), fams
+    assert torch.equal(out[1], out[3]) and torch.equal(traj[1], traj[3])
+    check("unet_t2a_kept_full_tiles_vs_reference", out[3][:g["y"].shape[0]], g["y"], 2e-4)
+
+
 def test_conv_item_order_does_not_change_results(golden):
     """The (K slice, tile) work items of a split-K convolution launch are walked slice-major (default since round 6: an XCD's
     contiguous eighth of the items belongs to one K slice, so its L2 streams 1 / S of the packed weights) or tile-major (round

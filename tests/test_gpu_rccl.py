@@ -21,7 +21,7 @@ def _bench(tmp_path, name, extra, port):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--ddim-steps", "5",
-           "--no-cpu-baseline", "--no-roofline", "--no-secondary", "--json-out", out] + extra
+           "--no-cpu-baseline", "--no-roofline", "--no-secondary", "--no-one-batch", "--json-out", out] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
@@ -29,11 +29,17 @@ def _bench(tmp_path, name, extra, port):
     return json.load(open(out)), json.loads(lines[0])
 
 
+_PLAIN = {}
+
+
 @pytest.mark.parametrize("inflight", [3, 1])
 def test_rccl_world_of_one_runs_the_collective_branches(tmp_path, inflight):
     from tests.util import free_port
-    plain, _ = _bench(tmp_path, "plain", ["--inflight", str(inflight)], free_port())
+    if "run" not in _PLAIN:      # the plain single-process run, once: every step generates the same prompts, whatever is in flight
+        _PLAIN["run"] = _bench(tmp_path, "plain", ["--inflight", "1"], free_port())[0]
+    plain = _PLAIN["run"]
     forced, line = _bench(tmp_path, "forced", ["--inflight", str(inflight), "--force-collectives"], free_port())
+    assert forced["config"]["batches_in_flight"] == inflight
     assert forced["ranks_seen"]["n_distinct"] == 1 and forced["ranks_seen"]["ids"][0].startswith(("pci:", "uuid:", "cuda-index:"))
     assert len(forced["per_rank_value"]) == 1 and forced["per_rank_value"][0] > 0
     assert "ranks_seen" not in plain

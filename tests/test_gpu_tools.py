@@ -29,6 +29,26 @@ def _rms(a, b):
     return float(((a - b) ** 2).mean().sqrt())
 
 
+# One model object per (class, precision) for the whole module: building one means generating and packing ~1 GB of seeded weights
+# (UNet + VAE + BigVGAN), several seconds each, and the driver runs this suite serially inside a fixed time limit.
+_CACHE = {}
+
+
+def _cached(kind, precision="bf16x3"):
+    key = (kind, precision)
+    if key not in _CACHE:
+        from audiogpt_amd.ldm.latent_diffusion import LatentDiffusionAudio
+        from audiogpt_amd.tools import I2A, T2A, Inpaint
+        make = {"ldm_t2a": lambda: LatentDiffusionAudio(C.LDM_T2A, device="cuda:0", precision=precision),
+                "T2A": lambda: T2A("cuda:0", precision=precision), "I2A": lambda: I2A("cuda:0", precision=precision),
+                "Inpaint": lambda: Inpaint("cuda:0", precision=precision)}[kind]
+        _CACHE[key] = make()
+    return _CACHE[key]
+
+
+_ORACLE_T2A = {}      # the CPU oracle chain of the T2A test does not depend on the precision under test: computed once
+
+
 # ------------------------------------------------------------------------------------------------ sampler + model object
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_ddim_sampler_and_model_surface_match_reference(golden, precision):
@@ -36,7 +56,7 @@ def test_ddim_sampler_and_model_surface_match_reference(golden, precision):
     apply_model / decode_first_stage / encode_first_stage vs the reference modules' goldens."""
     from audiogpt_amd.ldm.ddim import DDIMSampler
     from audiogpt_amd.ldm.latent_diffusion import DiagonalGaussianDistribution, LatentDiffusionAudio
-    model = LatentDiffusionAudio(C.LDM_T2A, device="cuda:0", precision=precision)
+    model = _cached("ldm_t2a", precision)
     assert model.precision == precision and model.ctx.precision == precision
     sampler = DDIMSampler(model)
     gd = golden("ddim_t2a_s10")
@@ -81,7 +101,7 @@ def test_ddim_sampler_mask_eta_intermediates_match_reference(golden, precision):
     from audiogpt_amd.ldm.ddim import DDIMSampler
     from audiogpt_amd.ldm.latent_diffusion import LatentDiffusionAudio
     g = golden("ddim_t2a_mask_eta_s6")
-    model = LatentDiffusionAudio(C.LDM_T2A, device="cuda:0", precision=precision)
+    model = _cached("ldm_t2a", precision)
     sampler = DDIMSampler(model)
     t = lambda k: torch.from_numpy(g[k]).cuda()
     kw = dict(S=int(g["S"]), conditioning=t("c"), batch_size=2, shape=[4, 10, 78], verbose=False, eta=float(g["eta"]),
@@ -129,7 +149,7 @@ def test_ddim_sampler_mask_eta_intermediates_match_reference(golden, precision):
 def test_T2A_txt2audio_matches_oracle_chain(precision):
     from audiogpt_amd.tools import T2A
     from oracle import ddim as O_ddim, unet as O_unet, vae as O_vae, vocoder as O_voc
-    t2a = T2A("cuda:0", precision=precision)
+    t2a = _cached("T2A", precision)
     assert t2a.sampler.model.ctx.precision == precision and t2a.vocoder.ctx is t2a.sampler.model.ctx
     text, S = "a dog barking in the rain", 10
     sr, wav = t2a.txt2audio(text, ddim_steps=S, n_samples=1)
@@ -142,10 +162,13 @@ def test_T2A_txt2audio_matches_oracle_chain(precision):
     usd = WT.make_unet_state_dict(C.UNET_T2A, seed=0)
     vsd = WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1)
     gsd = WT.make_vocoder_state_dict(C.BIGVGAN_16K, seed=3)
-    with torch.no_grad():
-        z = O_ddim.ddim_sample(lambda x, t, cc: O_unet.unet_forward(usd, C.UNET_T2A, x, t, cc), _ac(C.LDM_T2A), S, x_T, c, uc, 1.5)
-        spec = torch.clamp((O_vae.decode_first_stage(vsd, C.VAE_DDCONFIG, z, 1.0) + 1.0) / 2.0, 0.0, 1.0)[:, 0]
-        wav_ref = O_voc.bigvgan_forward(O_voc.fold_weight_norm(gsd), C.BIGVGAN_16K, spec)[0, 0].numpy()
+    key = (c.numpy().tobytes(), uc.numpy().tobytes(), S)
+    if key not in _ORACLE_T2A:
+        with torch.no_grad():
+            z = O_ddim.ddim_sample(lambda x, t, cc: O_unet.unet_forward(usd, C.UNET_T2A, x, t, cc), _ac(C.LDM_T2A), S, x_T, c, uc, 1.5)
+            spec = torch.clamp((O_vae.decode_first_stage(vsd, C.VAE_DDCONFIG, z, 1.0) + 1.0) / 2.0, 0.0, 1.0)[:, 0]
+            _ORACLE_T2A[key] = O_voc.bigvgan_forward(O_voc.fold_weight_norm(gsd), C.BIGVGAN_16K, spec)[0, 0].numpy()
+    wav_ref = _ORACLE_T2A[key]
     rms = _rms(wav, wav_ref)
     record(f"tools_{precision}_T2A.txt2audio_s{S}", wav_rms=rms, tol=1e-4)
     assert rms <= 1e-4, rms
@@ -156,7 +179,7 @@ def test_T2A_inference_writes_a_wav_file(tmp_path, monkeypatch):
     the keyword arguments is kept, so the step count is patched down for the test's sake."""
     from audiogpt_amd.tools import T2A
     monkeypatch.chdir(tmp_path)
-    t2a = T2A("cuda:0")
+    t2a = _cached("T2A")
     orig = t2a.txt2audio
     monkeypatch.setattr(t2a, "txt2audio", lambda text, H, W: orig(text, ddim_steps=2, n_samples=2, H=H, W=W))
     name = t2a.inference("rain on a tin roof")
@@ -170,7 +193,7 @@ def test_T2A_inference_writes_a_wav_file(tmp_path, monkeypatch):
 def test_I2A_img2audio_matches_oracle_chain():
     from audiogpt_amd.tools import I2A
     from oracle import ddim as O_ddim, unet as O_unet, vae as O_vae, vocoder as O_voc
-    i2a = I2A("cuda:0", precision="bf16x3")
+    i2a = _cached("I2A")
     image = np.random.RandomState(3).rand(64, 64, 3).astype(np.float32)
     S = 4
     sr, wav = i2a.img2audio(image, ddim_steps=S)
@@ -199,7 +222,7 @@ def test_Inpaint_inference_mel_matches_oracle_chain():
     DDIM without CFG, decode, compositing with the input mel, BigVGAN."""
     from audiogpt_amd.tools import Inpaint
     from oracle import ddim as O_ddim, unet as O_unet, vae as O_vae, vocoder as O_voc
-    inp = Inpaint("cuda:0", precision="bf16x3")
+    inp = _cached("Inpaint")
     rs = np.random.RandomState(9)
     mel_in = rs.rand(80, 900).astype(np.float32)          # longer than 848: cropped as the reference does
     mask = np.zeros((80, 700), dtype=np.float32)          # shorter than 848: zero-padded
@@ -243,7 +266,7 @@ def test_Inpaint_inference_files_in_files_out(tmp_path, monkeypatch):
 
     from audiogpt_amd.tools import Inpaint
     monkeypatch.chdir(tmp_path)
-    inp = Inpaint("cuda:0")
+    inp = _cached("Inpaint")
     sr = 16000
     t = np.arange(12 * sr) / sr
     wav = (0.3 * np.sin(2 * np.pi * (200 + 40 * t) * t) * 32767).astype(np.int16)
@@ -278,7 +301,7 @@ def test_Inpaint_show_mel_fn_is_the_registered_tool(tmp_path, monkeypatch):
     from audiogpt_amd.tools import Inpaint
     from oracle import resampy as R
     monkeypatch.chdir(tmp_path)
-    inp = Inpaint("cuda:0")
+    inp = _cached("Inpaint")
     assert inp.cmap_transform is matplotlib.cm.viridis                                   # audio-chatgpt.py:424
     rs = np.random.RandomState(7)
     cases = {}
