@@ -576,10 +576,13 @@ int maa_op_conv(maa_ctx* ctx, const float* d_x, int B, int Cin, int H, int W, co
         maa::WeightStore ws(ctx->c.dtype != 0);
         maa::Ctx& c = ctx->c;
         maa::PackedW pw = ws.pack_conv(s.sd, "w", h_bias ? "b" : "", KH, KW);
+        maa::PackedW pw4;      // Upsample + conv3x3: the four-phase form the models take in the bf16 modes (blocks.cpp conv_up2_into)
+        if (upsample2 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1 && leaky_slope == 0.f)
+            pw4 = ws.pack_conv_up2(s.sd, "w", h_bias ? "b" : "");
         maa::run_sized(c, [&] {
             maa::T4 x = maa::alloc_t(c, B, H, W, Cin);
             maa::launch_nchw_to_nhwc(c, d_x, B, Cin, H * W, x.p);
-            if (op_presplit(c, Cin, leaky_slope != 0.f)) {
+            if (!pw4.w && op_presplit(c, Cin, leaky_slope != 0.f)) {
                 maa::T4 xs = maa::alloc_t(c, B, H, W, Cin);
                 maa::launch_split32_pack(c, x.p, (long long)B * H * W, Cin, xs.p);
                 xs.split = true;
@@ -597,7 +600,7 @@ int maa_op_conv(maa_ctx* ctx, const float* d_x, int B, int Cin, int H, int W, co
                 o.a_act = 1;
                 o.a_slope = leaky_slope;
             }
-            maa::conv_into(c, x, nullptr, pw, o, y);
+            if (!(pw4.w && maa::conv_up2_into(c, x, pw4, y))) maa::conv_into(c, x, nullptr, pw, o, y);
             maa::launch_nhwc_to_nchw(c, y.p, B, Cout, Ho * Wo, d_y, Cout);
         });
         MAA_HIP(hipStreamSynchronize(c.stream));

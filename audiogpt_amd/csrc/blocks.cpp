@@ -58,6 +58,43 @@ void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const Con
     launch_igemm(ctx, p);
 }
 
+bool conv_up2_into(Ctx& ctx, const T4& x, const PackedW& w4, T4& out) {
+    if (!ctx.tune.up2 || !w4.w || w4.phase_rows == 0 || ctx.dtype == 0 || x.split || x.C % 32 != 0 || x.ld != 0) return false;
+    MAA_CHECK(out.B == x.B && out.H == 2 * x.H && out.W == 2 * x.W && out.C == w4.N, "conv_up2: output shape");
+    const size_t mk = ctx.ws.mark();
+    const long long M = x.rows();
+    float* xs = ctx.ws.alloc_f((size_t)x.numel());                  // the source as split32 rows (8 MB at the UNet's 5 x 39 level)
+    float* planes = ctx.ws.alloc_f((size_t)4 * M * out.C);          // [4 phases][B, H, W, C]
+    IGemm p;
+    p.a1 = xs;
+    p.lda1 = x.C;
+    p.C1 = x.C;
+    p.a_split = 1;
+    p.Hin = p.Hout = x.H;
+    p.Win = p.Wout = x.W;
+    p.KH = p.KW = 2;
+    p.ph = p.pw = 1;
+    p.b = w4.w;
+    p.ldb = w4.ld;
+    p.b_nk = w4.nk;
+    p.b_split = w4.split;
+    p.M = (int)M;
+    p.K = 4 * x.C;
+    p.N = out.C;
+    p.bias = w4.bias;
+    p.c = planes;
+    p.ldc = out.C;
+    p.ldr = out.C;
+    p.ldc2 = out.C;
+    p.zeros = ctx.zeros;
+    MAA_CHECK(p.K == w4.K, "conv_up2 weight K mismatch");
+    if (!ctx.ws.dry) launch_split32_pack(ctx, x.p, M, x.C, xs);
+    const bool ok = launch_igemm_pp_up2(ctx, p, w4.Npad, (long long)w4.phase_rows * w4.ld);
+    if (ok) launch_pixel_shuffle2(ctx, planes, x.B, x.H, x.W, out.C, out.p);
+    ctx.ws.release(mk);
+    return ok;
+}
+
 void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const PackedW& w, const float* res,
                  int ldr, float* out, int ldc, int geglu, int a_act, long long a_split_rows, int c_split, int act) {
     IGemm p;

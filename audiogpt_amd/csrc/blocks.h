@@ -46,6 +46,9 @@ struct ConvOpt {
 // out = conv(x1 ++ x2) with packed weight `w`; output spatial size given by (Ho, Wo)
 void conv_into(Ctx& ctx, const T4& x1, const T4* x2, const PackedW& w, const ConvOpt& o, T4& out);
 // linear over rows of a [rows, K] matrix (any leading layout, row pitch lda)
+// Upsample (nearest 2x) + conv3x3 as four 2x2 phase convolutions of the low-resolution source (4 / 9 of the multiplications; bf16
+// modes, weights from WeightStore::pack_conv_up2).  false: not applicable here -- the caller runs the 3x3 convolution with ConvOpt::up
+bool conv_up2_into(Ctx& ctx, const T4& x, const PackedW& w4, T4& out);
 void linear_into(Ctx& ctx, const float* a, int lda, long long rows, int K, const PackedW& w, const float* res,
                  int ldr, float* out, int ldc, int geglu = 0, int a_act = 0, long long a_split_rows = 0,
                  int c_split = 0, int act = 0);

@@ -78,6 +78,8 @@ struct PPArgs {
     float* part;         // split-K slabs or null
     int S, tile_major;   // K slices; 1: the slices of a tile are neighbours in the item order (one XCD writes a tile's slabs, the XCD
                          // whose reduce blocks read them and whose rows the consumer reads: xcd_contiguous, maa_internal.h), 0: slice-major
+    int tiles_pp;        // UP2: tiles of ONE phase (items = 4 phases x tiles_pp); phase = (py, px) of the 2x-upsampled output pixel
+    long long b_phase;   // UP2: floats between the packed weights of consecutive phases
     int dbg;             // TUNE instantiation only (MAA_PP_DBG): 1 no MFMAs, 2 no copies after the prologue, 4 no fragment reads, 8 no vmcnt wait
 };
 
@@ -91,7 +93,12 @@ struct PPArgs {
 // has no scratch at all
 // TERMS: 3 = bf16x3; 1 = the context's plain-bf16 mode: the hi halves of the same split32 lines are the operands (one MFMA per
 // k-step, the lo halves are staged with their lines but never read) -- the same schedule, a third of the matrix phase
-template <int MI, int NI, int GWM, int GWN, int NPA, bool TUNE, bool PERSIST, int OUT, int TERMS>
+// UP2: "nearest-2x upsample, then 3x3 convolution" (openaimodel.py:116-118, model.py:52-56) as FOUR 2x2 convolutions of the
+// low-resolution input, one per parity (py, px) of the output pixel: the 3x3 taps that read the same source pixel are summed into one
+// weight at load (runtime.cpp pack_conv_up2) -- 4 / 9 of the multiplications.  One launch: item -> (phase, tile); a phase has its
+// own packed weights (b + phase * b_phase), padding (ph, pw) = (1 - py, 1 - px) and output plane (c + phase * M * ldc, interleaved
+// into the image by pixel_shuffle2_kernel afterwards).  No K split (OUT = 1).
+template <int MI, int NI, int GWM, int GWN, int NPA, bool TUNE, bool PERSIST, int OUT, int TERMS, bool UP2 = false>
 __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPArgs q) {
     constexpr int BN = GWN * NI * 32;
     constexpr int BPG = BN / 16;                    // weight pieces (8 rows x 128 B) per group and chunk: half a chunk
@@ -131,6 +138,8 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
     const int W = q.W, H = q.H;
     const long long Mtot = p.M;
     int item = 0, m0 = 0, n0 = 0, c_begin = 0, c_end = 0, NQ = 0, cur_slab = 0;
+    int phase = 0, ph_i = q.ph, pw_i = q.pw, padflat_i = q.padflat;      // (UP2: per item; else the launch's)
+    const char* b_i = reinterpret_cast<const char*>(p.b);
 
     // zero line (read by lanes whose tap is outside the image)
     if (tid < 8) *reinterpret_cast<f32x4*>(sZ + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -171,15 +180,23 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         item = w_lo + w;
         // (the quotients are wave-uniform but come out of the VALU's division sequence: back into SGPRs)
         const int slice = __builtin_amdgcn_readfirstlane(q.tile_major ? item % q.S : item / q.tiles);
-        const int tile = __builtin_amdgcn_readfirstlane(q.tile_major ? item / q.S : item - slice * q.tiles);
+        int tile = __builtin_amdgcn_readfirstlane(q.tile_major ? item / q.S : item - slice * q.tiles);
         cur_slab = slice * q.tiles + tile;
+        if constexpr (UP2) {
+            phase = __builtin_amdgcn_readfirstlane(tile / q.tiles_pp);
+            tile -= phase * q.tiles_pp;
+            ph_i = 1 - (phase >> 1);
+            pw_i = 1 - (phase & 1);
+            padflat_i = ph_i * W + pw_i;
+            b_i = reinterpret_cast<const char*>(p.b) + (long long)phase * q.b_phase * 4;
+        }
         const int mt = __builtin_amdgcn_readfirstlane(tile / q.ntiles), nt = tile - mt * q.ntiles;
         m0 = mt * BM;
         n0 = nt * BN;
         c_begin = slice * q.cps;
         c_end = min(q.nci, c_begin + q.cps);
         NQ = (c_end - c_begin) * TAPS;
-        a_P0 = m0 - q.padflat + r8;
+        a_P0 = m0 - padflat_i + r8;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const long long m = (long long)m0 + a_r[i];
@@ -187,7 +204,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
             if (m < Mtot) {
                 const int ox = (int)(m % W), oy = (int)((m / W) % H);
                 for (int t = 0; t < TAPS; ++t) {
-                    const int iy = oy + (t / q.KW) * q.dh - q.ph, ix = ox + (t % q.KW) * q.dw - q.pw;
+                    const int iy = oy + (t / q.KW) * q.dh - ph_i, ix = ox + (t % q.KW) * q.dw - pw_i;
                     if (iy >= 0 && iy < H && ix >= 0 && ix < W) v |= 1u << t;
                 }
             }
@@ -198,13 +215,13 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
             const int pb = grp * BPG + k * 4 + wq;
             const int nl = 8 * pb + r8;
             const int n = min(n0 + nl, q.Nb - 1);          // rows past the last one: clamped, their columns are never stored
-            gpb[k] = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4);
+            gpb[k] = b_i + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4);
         }
     };
     // any piece (prologue)
     auto issue_a_any = [&](int ci, int pa) __attribute__((always_inline)) {
         const int line = pa * 8 + r8;
-        const int P = min(max(m0 - q.padflat + line, 0), Mlast);
+        const int P = min(max(m0 - padflat_i + line, 0), Mlast);
         const char* src = a_base + ((unsigned long long)(unsigned)P * lda4 + (unsigned long long)ci * 128u) + ((sl ^ ((line >> 1) & 7)) << 4);
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + pa * 1024), 16, 0, 0);      // (the first chunk starts at line 0)
     };
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
             for (int pb = wid; pb < BN / 8; pb += 8) {
                 const int nl = 8 * pb + r8;
                 const int n = min(n0 + nl, q.Nb - 1);
-                const char* src = reinterpret_cast<const char*>(p.b) + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4) +
+                const char* src = b_i + (long long)n * p.ldb * 4 + ((sl ^ ((nl >> 1) & 7)) << 4) +
                                   ((long long)j * C4 + (long long)c_begin * 128);
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sB + j * (BN * 128) + pb * 1024), 16, 0, 0);
             }
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         }
         // Every fragment read of this item is done (a wave gets here through the barrier that follows group 1's last memory
         // phase): the next item's first copies may overwrite the rings while this item's results are stored.
-        const int e_slab = cur_slab, e_m0 = m0, e_n0 = n0;
+        const int e_slab = cur_slab, e_m0 = m0, e_n0 = n0, e_phase = phase;
         const int w_next = w_cur + w_step;
         bool more = false;
         if constexpr (PERSIST) {
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(512) void igemm_pp_kernel(const IGemm p, const PPAr
         const int rpb = p.Hout * p.Wout;
         const int row_base = e_m0 + grp * 128 + wm * (32 * MI), col_base = e_n0 + wn * (32 * NI);
         if (OUT == 1 || (OUT == 0 && q.part == nullptr)) {
-            igemm_epilogue<MI, NI>(p, acc, row_base, col_base, lrow, lk, 0, q.Nb, rpb);
+            igemm_epilogue<MI, NI>(p, acc, row_base, col_base, lrow, lk, UP2 ? (long long)e_phase * p.M * p.ldc : 0LL, q.Nb, rpb);
         } else {
             // slab of this (slice, tile): [MI NI blocks][4 register quads][512 threads][4 floats]
             float* pp = q.part + ((long long)e_slab * (MI * NI * 4) * 512 + tid) * 4;
@@ -510,6 +527,8 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     // streamed the whole weight tensor: FETCH_SIZE x 3.4 at the 5 x 39 level for the same run time (profiles/r5/r5_bf16x3_pmc_fetch_write.txt)
     q.tile_major = ctx.tune.pp_tile_major && pl.S > 1 ? 1 : 0;
     q.dbg = 0;
+    q.tiles_pp = q.tiles;
+    q.b_phase = 0;
     MAA_CHECK((q.nci + q.cps - 1) / q.cps == pl.S, "igemm_pp: K split leaves an empty slice");
     MAA_CHECK(q.CAPl > 0, "igemm_pp: the A ring does not fit beside the weight ring");
     const size_t lds = (size_t)q.CAPl * 128 + (size_t)NSB * BN * 128 + 128 + 1024;
@@ -525,6 +544,59 @@ void launch_one(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, float*
     else
         launch_npa<MI, NI, GWM, GWN, 3>(ctx, p, q, grid, lds);
     if (pl.S > 1) launch_splitk_reduce(ctx, p, part, pl.S, q.tiles, ntiles, Nb, BM, BN, GWN, MI, NI, 512);
+}
+
+// Upsample + 3x3 convolution as four 2x2 phase convolutions in one launch (see the kernel's UP2 note).  `p` describes ONE phase:
+// KH = KW = 2, the low-resolution geometry (Hin = Hout, Win = Wout), M = B H W, K = 4 C1, c = the phase-major plane buffer
+// [4][M][ldc]; b_phase = floats between the phases' packed weights.
+template <int MI, int NI, int GWM, int GWN>
+void launch_up2(const Ctx& ctx, const IGemm& p, int Nb, long long b_phase) {
+    constexpr int BN = GWN * NI * 32;
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.N + BN - 1) / BN;
+    const PPGeom g = pp_geom(p);
+    PPArgs q;
+    q.W = p.Win;
+    q.H = p.Hin;
+    q.T = g.T;
+    q.KW = g.KW;
+    q.rowstep = g.rowstep;
+    q.colstep = g.colstep;
+    q.dh = p.dh;
+    q.dw = p.dw;
+    q.ph = 1;
+    q.pw = 1;
+    q.padflat = p.Win + 1;
+    q.NLp = g.NLp;
+    q.CAPl = pp_ring_lines(g, BN);
+    q.ntiles = ntiles;
+    q.tiles_pp = mtiles * ntiles;
+    q.tiles = 4 * q.tiles_pp;
+    q.nci = p.C1 / BK;
+    q.cps = q.nci;
+    q.Nb = Nb;
+    q.part = nullptr;
+    q.S = 1;
+    q.tile_major = 0;
+    q.b_phase = b_phase;
+    q.dbg = 0;
+    MAA_CHECK(q.CAPl > 0, "igemm_pp up2: the A ring does not fit beside the weight ring");
+    const size_t lds = (size_t)q.CAPl * 128 + (size_t)NSB * BN * 128 + 128 + 1024;
+    MAA_CHECK(lds <= 163840, "igemm_pp up2: LDS per workgroup");
+    q.items = q.tiles;
+    const int cus = device_cu_count(ctx.device);
+    const int grid = q.items < cus ? q.items : cus;
+    auto go = [&](auto kern) {
+        ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ctx.device, 163840);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, ctx.stream, p, q);
+    };
+    const bool one = ctx.dtype == 2;
+    if (g.npa == 1) {
+        if (one) go(igemm_pp_kernel<MI, NI, GWM, GWN, 1, false, true, 1, 1, true>);
+        else go(igemm_pp_kernel<MI, NI, GWM, GWN, 1, false, true, 1, 3, true>);
+    } else {
+        if (one) go(igemm_pp_kernel<MI, NI, GWM, GWN, 3, false, true, 1, 1, true>);
+        else go(igemm_pp_kernel<MI, NI, GWM, GWN, 3, false, true, 1, 3, true>);
+    }
 }
 
 
@@ -820,6 +892,30 @@ void launch_igemm_pp(const Ctx& ctx, const IGemm& p, int Nb, const PPPlan& pl, f
         launch_one<1, 5, 4, 1>(ctx, p, Nb, pl, part);
 }
 
+
+// The phase form of "nearest-2x upsample + 3x3 convolution" (bf16 modes, split32 source and weights, a whole number of 32-channel
+// chunks, rings that fit): false = not taken, the caller runs the 3x3 convolution through the virtual upsample gather.
+bool launch_igemm_pp_up2(const Ctx& ctx, const IGemm& p, int Nb, long long b_phase) {
+    if (ctx.dtype == 0 || (!ctx.tune.pp.empty() && ctx.tune.pp[0] == 'o')) return false;
+    if (!(p.KH == 2 && p.KW == 2 && p.sh == 1 && p.sw == 1 && p.dh == 1 && p.dw == 1 && p.up == 0)) return false;
+    if (!(p.a_split && p.b_split && p.b_nk && p.C2 == 0 && p.C1 % BK == 0 && p.Z == 1 && p.a_act == 0 && !p.geglu)) return false;
+    if (p.Hout != p.Hin || p.Wout != p.Win || p.K != 4 * p.C1 || p.N < 64 || p.C1 / BK < 1) return false;
+    const PPGeom g = pp_geom(p);
+    if (g.npa == 0) return false;
+    int bn = (p.N % 160 == 0 && pp_ring_lines(g, 160) > 0) ? 160 : 128;
+    if (pp_ring_lines(g, bn) <= 0) return false;
+    if (ctx.ws.dry) return true;
+    const int terms = ctx.dtype == 2 ? 1 : 3;
+    const char* name = terms == 1 ? (bn == 160 ? "igemm_pp_up2_bf16<256x160>" : "igemm_pp_up2_bf16<256x128>")
+                                  : (bn == 160 ? "igemm_pp_up2_bf16x3<256x160>" : "igemm_pp_up2_bf16x3<256x128>");
+    ProfScope prof(ctx, name, 2.0 * 4.0 * p.M * (double)p.N * p.K, 4.0 * (4.0 * p.K * p.N + 4.0 * p.M * p.N));
+    if (bn == 128)
+        launch_up2<2, 2, 2, 2>(ctx, p, Nb, b_phase);
+    else
+        launch_up2<1, 5, 4, 1>(ctx, p, Nb, b_phase);
+    MAA_HIP(hipGetLastError());
+    return true;
+}
 
 // 1x1 / Linear problems (both operands split32, one source, a whole number of 32-deep chunks).  Without a K split the engine
 // is bit-identical to the others, so taking it may depend on M: only when the 256-row tiles fill a useful part of the chip.

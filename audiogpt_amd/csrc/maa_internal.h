@@ -132,6 +132,7 @@ struct Tuning {
     std::string dma2;                       // MAA_DMA2 = "off" | "0,4,1,S[,kmin[,kmax]]": the split-K LDS-DMA engine's policy override
     std::string pp, pp1;                    // MAA_PP / MAA_PP1 = "off" | "bn,S": tile width / K slices of the ping-pong engine (3x3 form, 1x1 form)
     int pp_s_narrow = 2, pp_s_wide = 4;     // MAA_PP_S = "a,b": K slices of the ping-pong engine's 3x3 layers with < 4 / >= 4 N tiles (10x78 / 5x39 in the UNet)
+    bool up2 = true;                        // MAA_UP2=0: Upsample + conv3x3 through the virtual-upsample gather (rounds 1-5) instead of the four-phase form
     bool pp_tile_major = false;             // MAA_PP_TILE_MAJOR=1: round 5's item order (a tile's K slices are neighbours); 0: slice-major (an XCD streams 1 / S of the weights)
     bool op_presplit = false;               // MAA_OP_PRESPLIT=1: the maa_op_* test entry points hand activations over as split32
     bool no_dma = false;                    // MAA_NO_DMA: every bf16 contraction on the register-staged engine (bit-identity tests)
@@ -275,6 +276,10 @@ void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, con
                       float eps, float* out, int out_split = 0);
 // fp32 [rows, C] -> split32 rows of the same pitch (C % 32 == 0): tests and micro-benchmarks of the engines that take
 // pre-split activations (in the models the normalisations write this form directly)
+// "nearest-2x upsample + 3x3 convolution" as four 2x2 phase convolutions in one launch of the ping-pong engine (igemm_pp.hip);
+// planes [4][B H W][C] -> image [B, 2H, 2W, C] (misc.hip)
+bool launch_igemm_pp_up2(const Ctx& ctx, const IGemm& p, int Nb, long long b_phase);
+void launch_pixel_shuffle2(const Ctx& ctx, const float* planes, int B, int H, int W, int C, float* out);
 void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, float* out, float slope = 1.f);
 void launch_split32_unpack(const Ctx& ctx, const float* x, long long rows, int C, float* out);      // hi + lo back to fp32 (tests)
 // fused softmax(alpha q k^T) v for the bf16 precision modes; false = shape not covered, use the GEMM path
@@ -344,6 +349,7 @@ using StateDict = std::map<std::string, HostTensor>;
 //   nk = 0: [K][Npad] (row pitch ld = Npad)    -- exact-fp32 mode
 //   nk = 1: [Npad][Kpad] (row pitch ld = K rounded up to 4, zero padded) -- bf16 modes (k-contiguous operands)
 struct PackedW {
+    int phase_rows = 0;     // pack_conv_up2: packed rows between the four phases' weights (0: an ordinary weight)
     float* w = nullptr;
     float* bias = nullptr;  // [Npad] or null
     int K = 0, N = 0, Npad = 0;
@@ -367,6 +373,9 @@ public:
     // upload a host [K][Npad] matrix in this store's layout and fill w / ld / nk
     // bf16_ok: every use of this weight is eligible for the bf16 engine (then it is stored pre-split)
     void finish(PackedW& pw, const std::vector<float>& kn, bool bf16_ok = false);
+    // the four 2x2 phase weights of "nearest-2x upsample + conv3x3" (taps reading the same source pixel summed); w == nullptr when
+    // this store's layout / the channel count does not allow the phase form
+    PackedW pack_conv_up2(const StateDict& sd, const std::string& wname, const std::string& bname);
     void* upload_raw(const void* host, size_t bytes);
     float* upload(const std::vector<float>& host);
     // conv / linear weight [Cout][Cin][KH][KW] (linear: KH=KW=1) -> [ (ky,kx,ci) ][Cout pad 32]

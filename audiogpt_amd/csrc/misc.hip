@@ -97,6 +97,23 @@ __global__ void spec_from_mel_kernel(const float* __restrict__ x, long long n, f
         out[i] = fminf(fmaxf((x[i] + 1.0f) / 2.0f, 0.0f), 1.0f);
 }
 
+// planes [4 = (py, px)][B, H, W, C] -> out [B, 2H, 2W, C]: the four phase outputs of the up2 convolution interleaved into the image
+// (16 bytes per thread; a pixel's C channels are one contiguous run on both sides)
+__global__ void pixel_shuffle2_kernel(const float4* __restrict__ planes, int B, int H, int W, int C4, float4* __restrict__ out) {
+    const long long n = (long long)B * H * W * 4 * C4;
+    const long long plane = (long long)B * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long r = i / C4;
+        const int ox = (int)(r % (2 * W));
+        r /= 2 * W;
+        const int oy = (int)(r % (2 * H));
+        const int b = (int)(r / (2 * H));
+        const int phase = (oy & 1) * 2 + (ox & 1);
+        out[i] = planes[phase * plane + (((long long)b * H + (oy >> 1)) * W + (ox >> 1)) * C4 + c];
+    }
+}
+
 __global__ void avgpool2_kernel(const float* __restrict__ x, int B, int H, int W, int C, float* __restrict__ out) {
     const int Ho = H / 2, Wo = W / 2;
     const long long n = (long long)B * Ho * Wo * C;
@@ -374,6 +391,11 @@ void launch_nchw_to_nhwc(const Ctx& ctx, const float* x, int B, int C, int HW, f
 }
 void launch_nhwc_to_nchw(const Ctx& ctx, const float* x, int B, int C, int HW, float* out, int ld_in) {
     MAA_LAUNCH1(nhwc_to_nchw_kernel, (long long)B * C * HW, x, B, C, HW, ld_in, out);
+}
+void launch_pixel_shuffle2(const Ctx& ctx, const float* planes, int B, int H, int W, int C, float* out) {
+    MAA_CHECK(C % 4 == 0, "pixel_shuffle2: channels must be a multiple of 4");
+    MAA_LAUNCH1(pixel_shuffle2_kernel, (long long)B * H * W * C, reinterpret_cast<const float4*>(planes), B, H, W, C / 4,
+                reinterpret_cast<float4*>(out));
 }
 void launch_avgpool2(const Ctx& ctx, const float* x, int B, int H, int W, int C, float* out) {
     MAA_LAUNCH1(avgpool2_kernel, (long long)B * (H / 2) * (W / 2) * C, x, B, H, W, C, out);

@@ -169,6 +169,7 @@ void Tuning::load() {
     if (pp_s_narrow < 1) pp_s_narrow = 1;
     if (pp_s_wide < 1) pp_s_wide = 1;
     pp_tile_major = get_s("MAA_PP_TILE_MAJOR") == "1";
+    up2 = get_s("MAA_UP2") != "0";
     const std::string ps = get_s("MAA_OP_PRESPLIT");
     op_presplit = !ps.empty() && ps[0] == '1';
     no_dma = !get_s("MAA_NO_DMA").empty();
@@ -357,6 +358,45 @@ PackedW WeightStore::pack_conv(const StateDict& sd, const std::string& wname, co
     if (!bname.empty()) {
         const HostTensor& b = get(sd, bname);
         std::vector<float> hb(pw.Npad, 0.f);
+        std::memcpy(hb.data(), b.data, sizeof(float) * Cout);
+        pw.bias = upload(hb);
+    }
+    return pw;
+}
+
+PackedW WeightStore::pack_conv_up2(const StateDict& sd, const std::string& wname, const std::string& bname) {
+    // out(2y + py, 2x + px) = sum_{ky, kx} w[ky][kx] . up(2y + py + ky - 1, 2x + px + kx - 1),  up(i, j) = x(i >> 1, j >> 1):
+    // py = 0: ky = 0 reads row y - 1, ky = 1, 2 read row y;   py = 1: ky = 0, 1 read row y, ky = 2 reads row y + 1 (same in x).
+    // Phase (py, px) is a 2x2 convolution over rows {y - 1 + py, y + py} x cols {x - 1 + px, x + px} = padding (1 - py, 1 - px),
+    // tap (ty, tx) = the sum of the 3x3 taps that land on it.  K = (ty, tx, ci); the phases are stacked on the N axis.
+    PackedW pw;
+    const HostTensor& w = get(sd, wname);
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1];
+    if (!nk_ || Cin % 32 != 0 || w.numel() != (long long)Cout * Cin * 9) return pw;
+    const int np = pad32(Cout);
+    pw.K = 4 * Cin;
+    pw.Npad = 4 * np;
+    std::vector<float> h((size_t)pw.K * pw.Npad, 0.f);
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const int phase = py * 2 + px;
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ty = py == 0 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0);
+                    const int tx = px == 0 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);
+                    const int t = ty * 2 + tx;
+                    for (int co = 0; co < Cout; ++co)
+                        for (int ci = 0; ci < Cin; ++ci)
+                            h[((size_t)t * Cin + ci) * pw.Npad + (size_t)phase * np + co] += w.data[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
+                }
+        }
+    finish(pw, h, true);
+    pw.N = Cout;
+    pw.Npad = np;
+    pw.phase_rows = np;
+    if (!bname.empty()) {
+        const HostTensor& b = get(sd, bname);
+        std::vector<float> hb(np, 0.f);
         std::memcpy(hb.data(), b.data, sizeof(float) * Cout);
         pw.bias = upload(hb);
     }

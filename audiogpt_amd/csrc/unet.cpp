@@ -45,7 +45,7 @@ struct AttnW {
     PackedW qkv, proj;
 };
 struct ConvW {
-    PackedW w;
+    PackedW w, w_up2;      // w_up2: the four 2x2 phase weights of an Upsample convolution (pack_conv_up2), else empty
     int cin = 0, cout = 0;
 };
 enum Kind { kConv, kRes, kST, kAttn, kDown, kUp };
@@ -159,6 +159,7 @@ struct UNet::Impl {
         c.cin = cin;
         c.cout = cout;
         c.w = ws.pack_conv(sd, p + "weight", p + "bias", 3, 3);
+        if (kind == kUp) c.w_up2 = ws.pack_conv_up2(sd, p + "weight", p + "bias");
         convs.push_back(c);
         return {kind, (int)convs.size() - 1};
     }
@@ -429,11 +430,13 @@ struct UNet::Impl {
                 }
                 case kUp: {     // Upsample: nearest 2x then conv3x3 (:116-118), the gather reads through the upsample
                     T4 o = alloc_t(ctx, h.B, h.H * 2, h.W * 2, convs[l.idx].cout);
-                    ConvOpt co;
-                    co.KH = co.KW = 3;
-                    co.pad = 1;
-                    co.up = 1;
-                    conv_into(ctx, h, nullptr, convs[l.idx].w, co, o);
+                    if (!conv_up2_into(ctx, h, convs[l.idx].w_up2, o)) {      // (exact-fp32 mode, odd channel counts, MAA_PP=off)
+                        ConvOpt co;
+                        co.KH = co.KW = 3;
+                        co.pad = 1;
+                        co.up = 1;
+                        conv_into(ctx, h, nullptr, convs[l.idx].w, co, o);
+                    }
                     h = o;
                     break;
                 }

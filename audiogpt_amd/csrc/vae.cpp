@@ -28,7 +28,7 @@ struct VLevel {
     std::vector<VResW> blocks;
     std::vector<VAttnW> attns;
     bool has_resample = false;
-    PackedW resample;
+    PackedW resample, resample_up2;
     int resample_c = 0;
 };
 }  // namespace
@@ -110,6 +110,8 @@ struct VAE::Impl {
                 L.resample_c = block_in;
                 L.resample = ws.pack_conv(sd, p + "up." + std::to_string(lvl) + ".upsample.conv.weight",
                                           p + "up." + std::to_string(lvl) + ".upsample.conv.bias", 3, 3);
+                L.resample_up2 = ws.pack_conv_up2(sd, p + "up." + std::to_string(lvl) + ".upsample.conv.weight",
+                                                  p + "up." + std::to_string(lvl) + ".upsample.conv.bias");
                 curr *= 2;
             }
         }
@@ -224,9 +226,11 @@ struct VAE::Impl {
             }
             if (L.has_resample) {
                 T4 up = alloc_t(ctx, B, hcur.H * 2, hcur.W * 2, L.resample_c);
-                ConvOpt ou = o3;
-                ou.up = 1;
-                conv_into(ctx, hcur, nullptr, L.resample, ou, up);
+                if (!conv_up2_into(ctx, hcur, L.resample_up2, up)) {
+                    ConvOpt ou = o3;
+                    ou.up = 1;
+                    conv_into(ctx, hcur, nullptr, L.resample, ou, up);
+                }
                 hcur = up;
             }
         }

@@ -199,3 +199,46 @@ def test_conv1d_dilated(ctx, k, dil, B, C, Cout, L):
     rows = ctx.prof_end()
     assert any(r.startswith("pp") for r in rows), rows.keys()
     check(f"pp_conv1d_k{k}_d{dil}_{C}_{Cout}_L{L}_b{B}", y, F.conv2d(x, w, b, padding=(0, pad), dilation=(1, dil)), TOL)
+
+
+UP2 = [  # B, Cin, Cout, H, W  (low-resolution source)
+    (16, 640, 640, 5, 39),     # the T2A UNet's Upsample at the benchmark's batch: 4 phases x 52 tiles of 256 x 160
+    (2, 640, 640, 5, 39),      # the golden's batch: ragged last M tile (390 rows)
+    (3, 320, 320, 10, 53),     # inpaint-like width, odd batch, two N tiles
+    (1, 512, 512, 10, 78),     # the VAE decoder's first Upsample
+    (2, 256, 256, 20, 156),    # ... its second: 128-wide tiles, persistent workgroups (items > CUs)
+    (2, 128, 128, 40, 312),    # ... its last: a chunk of 256 + W + 1 lines does not fit the A ring twice over -> the gather path (asserted)
+    (1, 96, 64, 7, 9),         # N = 64 (one padded 128-wide tile), three channel chunks, tiny image
+]
+
+
+@pytest.mark.parametrize("case", UP2, ids=lambda c: "x".join(map(str, c)))
+def test_upsample_conv_as_four_phase_convolutions(ctx, case):
+    """Upsample (nearest 2x) + conv3x3 (openaimodel.py:116-118; model.py:52-56) in the bf16 modes runs as four 2x2 convolutions of the
+    LOW-resolution source, one per parity of the output pixel, the 3x3 taps that read the same source pixel summed at load (4 / 9 of the
+    multiplications), in ONE launch of the ping-pong engine (UP2 instantiation) + a pixel shuffle: against
+    conv2d(interpolate(x, 2, "nearest")) in fp32 on the CPU, image borders and sample boundaries included; the kernel really ran;
+    a sample's rows do not depend on its batch; with MAA_PP=off the old gather path gives the same answer to tolerance."""
+    B, Cin, Cout, H, W = case
+    x = torch.randn(B, Cin, H, W, generator=g(B * 7 + W))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(Cin + Cout)) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g(5))
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    ctx.prof_begin()
+    y = ctx.op_conv(x, w, b, pad=1, up=True).cpu()
+    rows = ctx.prof_end()
+    if W >= 300:      # the phase form is not taken (LDS): same call, same answer, through the virtual-upsample gather
+        assert not any(k.startswith("igemm_pp_up2") for k in rows), rows.keys()
+        check(f"pp_up2_fallback_{'x'.join(map(str, case))}", y, ref, TOL)
+        return
+    assert any(k.startswith("igemm_pp_up2_bf16x3") for k in rows) and "pixel_shuffle2_kernel" in rows, rows.keys()
+    assert y.shape == ref.shape == (B, Cout, 2 * H, 2 * W)
+    check(f"pp_up2_{'x'.join(map(str, case))}", y, ref, TOL)
+    y1 = ctx.op_conv(x[:1], w, b, pad=1, up=True).cpu()
+    assert torch.equal(y1, y[:1])                                   # batch invariance, bit for bit
+    assert torch.equal(ctx.op_conv(x, w, b, pad=1, up=True).cpu(), y)      # deterministic
+    with forced("off", presplit=False):
+        ctx.prof_begin()
+        y_old = ctx.op_conv(x, w, b, pad=1, up=True).cpu()
+        assert not any(k.startswith("igemm_pp_up2") for k in ctx.prof_end())
+    check(f"pp_up2_vs_gather_{'x'.join(map(str, case))}", y, y_old, TOL)

@@ -85,7 +85,7 @@ def mfma_loops_without_scratch(body):
 
 def _pp_tune_build(name):
     """igemm_pp_kernel<MI, NI, GWM, GWN, NPA, TUNE, PERSIST, OUT, TERMS>: TUNE is the first bool of the mangled argument list."""
-    return "igemm_pp_kernel" in name and re.search(r"Li[13]ELb1ELb[01]ELi\dELi[13]EEEv", name) is not None
+    return "igemm_pp_kernel" in name and re.search(r"Li[13]ELb1ELb[01]ELi\dELi[13]ELb[01]EEEv", name) is not None
 
 
 def test_no_scratch_inside_any_mfma_loop(asm):
@@ -136,7 +136,7 @@ def test_register_budgets(asm):
                 continue
             # the 160-wide tile spills only where its result leaves through the fused epilogue (the vocoders' 1-D layers never
             # take it: they are 128 wide); the slab-only instantiations -- every 3x3 convolution of the UNet -- have no scratch
-            if "igemm_pp_kernel" in name and "ILi1ELi5E" in name and re.search(r"ELb[01]ELi1ELi[13]EEEv", name):      # OUT = 1
+            if "igemm_pp_kernel" in name and "ILi1ELi5E" in name and re.search(r"ELb[01]ELi1ELi[13]ELb[01]EEEv", name):      # OUT = 1
                 continue
             if "igemm_pp1_kernel" in name and "ILi1ELi5E" in name:      # (the 1x1 form's 160-wide tile: forced by MAA_PP1 only)
                 continue
