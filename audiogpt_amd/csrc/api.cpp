@@ -588,6 +588,10 @@ int maa_op_conv(maa_ctx* ctx, const float* d_x, int B, int Cin, int H, int W, co
                 xs.split = true;
                 x = xs;
             }
+            if (x.split && Cout <= 4 && h_bias && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dil == 1 && !upsample2 && c.tune.up2) {
+                maa::PackedW pn = ws.pack_narrow3x3(s.sd, "w", "b");      // the UNet's output convolution (unet.cpp forward_body)
+                if (maa::launch_narrow_conv3x3(c, x.p, Cin, B, H, W, Cin, pn.w, pn.bias, Cout, d_y)) return;
+            }
             maa::T4 y = maa::alloc_t(c, B, Ho, Wo, Cout);
             maa::ConvOpt o;
             o.KH = KH;

@@ -279,6 +279,10 @@ void launch_layernorm(const Ctx& ctx, const float* x, long long rows, int C, con
 // "nearest-2x upsample + 3x3 convolution" as four 2x2 phase convolutions in one launch of the ping-pong engine (igemm_pp.hip);
 // planes [4][B H W][C] -> image [B, 2H, 2W, C] (misc.hip)
 bool launch_igemm_pp_up2(const Ctx& ctx, const IGemm& p, int Nb, long long b_phase);
+// conv3x3 (stride 1, pad 1) to N <= 4 channels from split32 rows, output in NCHW (misc.hip; bf16x3 mode); w4 = [9][C] float4 of
+// weights in [tap][channel % 8][channel / 8] order (WeightStore::pack_narrow3x3), bias [4].  false: not applicable -> the implicit GEMM
+bool launch_narrow_conv3x3(const Ctx& ctx, const float* a_split, int lda, int B, int H, int W, int C, const float* w4, const float* bias,
+                           int N, float* out_nchw);
 void launch_pixel_shuffle2(const Ctx& ctx, const float* planes, int B, int H, int W, int C, float* out);
 void launch_split32_pack(const Ctx& ctx, const float* x, long long rows, int C, float* out, float slope = 1.f);
 void launch_split32_unpack(const Ctx& ctx, const float* x, long long rows, int C, float* out);      // hi + lo back to fp32 (tests)
@@ -376,6 +380,8 @@ public:
     // the four 2x2 phase weights of "nearest-2x upsample + conv3x3" (taps reading the same source pixel summed); w == nullptr when
     // this store's layout / the channel count does not allow the phase form
     PackedW pack_conv_up2(const StateDict& sd, const std::string& wname, const std::string& bname);
+    // conv3x3 with Cout <= 4 for launch_narrow_conv3x3: w = [9][Cin] float4 (tap, channel; the outputs in x y z w), bias = [4] floats
+    PackedW pack_narrow3x3(const StateDict& sd, const std::string& wname, const std::string& bname);
     void* upload_raw(const void* host, size_t bytes);
     float* upload(const std::vector<float>& host);
     // conv / linear weight [Cout][Cin][KH][KW] (linear: KH=KW=1) -> [ (ky,kx,ci) ][Cout pad 32]

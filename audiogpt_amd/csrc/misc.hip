@@ -97,6 +97,105 @@ __global__ void spec_from_mel_kernel(const float* __restrict__ x, long long n, f
         out[i] = fminf(fmaxf((x[i] + 1.0f) / 2.0f, 0.0f), 1.0f);
 }
 
+// 3x3 convolution (stride 1, padding 1) to a FEW output channels (N <= 4: the UNet's 320 -> 4 output convolution,
+// openaimodel.py:693-697) from split32 rows, written straight to NCHW.  The implicit-GEMM engines pad N to 32 and ran this layer
+// on 49 - 98 workgroups of 90 K chunks (58 us for 0.3 GFLOP); here a wave owns four consecutive output positions, a lane eight
+// channels (one 16-byte load of the hi halves and one of the lo halves per tap and position; x = hi + lo, 2^-17 relative), the
+// weights sit in LDS as one float4 per (tap, channel) and are read once per four positions, the products are fp32 FMAs (more
+// exact than the bf16x3 MFMA), the 16 partial sums are reduced across the wave at the end.
+__global__ __launch_bounds__(256) void narrow_conv3x3_kernel(const float* __restrict__ a, int lda, int B, int H, int W, int C,
+                                                            const float4* __restrict__ w4, const float* __restrict__ bias, int N,
+                                                            float* __restrict__ out_nchw) {
+    extern __shared__ __attribute__((aligned(16))) float4 sw[];      // [9 taps][8 k][C / 8 groups]: channel 8 g + k of tap t
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 9 * C; i += 256) sw[i] = w4[i];
+    __syncthreads();
+    const int HW = H * W;
+    const long long M = (long long)B * HW;
+    const long long m0 = ((long long)blockIdx.x * 4 + wid) * 4;
+    if (m0 >= M) return;
+    int py[4], px[4];
+    bool live[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const long long m = m0 + p;
+        live[p] = m < M;
+        const int r = (int)((live[p] ? m : 0) % HW);
+        py[p] = r / W;
+        px[p] = r - py[p] * W;
+    }
+    float acc[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[p][n] = 0.f;
+    const char* ab = reinterpret_cast<const char*>(a);
+    // (measured, round 6: fetching the next tap's pieces before multiplying this one costs 70 more VGPRs and doubles the kernel's
+    // time; unrolling the taps spills)
+    for (int g = lane; g < C / 8; g += 64) {
+        const long long goff = (long long)(g >> 2) * 128 + (g & 3) * 16;      // hi halves of channels 8 g .. 8 g + 7 inside a row
+        for (int t = 0; t < 9; ++t) {
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            float x[4][8];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int iy = py[p] + dy, ix = px[p] + dx;
+                const bool ok = live[p] && iy >= 0 && iy < H && ix >= 0 && ix < W;      // wave-uniform
+                if (ok) {
+                    const char* row = ab + ((m0 + p) + (long long)dy * W + dx) * (long long)lda * 4 + goff;
+                    const uint4 hi = *reinterpret_cast<const uint4*>(row);
+                    const uint4 lo = *reinterpret_cast<const uint4*>(row + 64);
+                    const unsigned hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        x[p][2 * k] = __builtin_bit_cast(float, hw[k] << 16) + __builtin_bit_cast(float, lw[k] << 16);
+                        x[p][2 * k + 1] = __builtin_bit_cast(float, hw[k] & 0xffff0000u) + __builtin_bit_cast(float, lw[k] & 0xffff0000u);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) x[p][k] = 0.f;
+                }
+            }
+            const int G = C >> 3;
+            const float4* wt = sw + (t * 8) * G + g;      // [tap][k][g]: the lanes of a wave read consecutive float4 (no bank conflicts)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 wv = wt[k * G];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    acc[p][0] = fmaf(x[p][k], wv.x, acc[p][0]);
+                    acc[p][1] = fmaf(x[p][k], wv.y, acc[p][1]);
+                    acc[p][2] = fmaf(x[p][k], wv.z, acc[p][2]);
+                    acc[p][3] = fmaf(x[p][k], wv.w, acc[p][3]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            float v = acc[p][n];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            acc[p][n] = v;
+        }
+    if (lane < 16) {
+        const int p = lane >> 2, n = lane & 3;
+        const long long m = m0 + p;
+        if (m < M && n < N) {
+            float v = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn)
+                    if (pp == p && nn == n) v = acc[pp][nn];
+            const long long b = m / HW;
+            out_nchw[(b * N + n) * HW + (m - b * HW)] = v + bias[n];
+        }
+    }
+}
+
 // planes [4 = (py, px)][B, H, W, C] -> out [B, 2H, 2W, C]: the four phase outputs of the up2 convolution interleaved into the image
 // (16 bytes per thread; a pixel's C channels are one contiguous run on both sides)
 __global__ void pixel_shuffle2_kernel(const float4* __restrict__ planes, int B, int H, int W, int C4, float4* __restrict__ out) {
@@ -391,6 +490,19 @@ void launch_nchw_to_nhwc(const Ctx& ctx, const float* x, int B, int C, int HW, f
 }
 void launch_nhwc_to_nchw(const Ctx& ctx, const float* x, int B, int C, int HW, float* out, int ld_in) {
     MAA_LAUNCH1(nhwc_to_nchw_kernel, (long long)B * C * HW, x, B, C, HW, ld_in, out);
+}
+bool launch_narrow_conv3x3(const Ctx& ctx, const float* a_split, int lda, int B, int H, int W, int C, const float* w4, const float* bias,
+                           int N, float* out_nchw) {
+    const size_t lds = (size_t)9 * C * sizeof(float4);
+    if (ctx.dtype != 1 || N > 4 || C % 32 != 0 || lds > 98304 || !w4 || !bias) return false;
+    if (ctx.ws.dry) return true;
+    const long long M = (long long)B * H * W;
+    ProfScope prof(ctx, "narrow_conv3x3_kernel", 2.0 * M * N * 9.0 * C, 4.0 * M * C);
+    ensure_dynamic_lds(reinterpret_cast<const void*>(narrow_conv3x3_kernel), ctx.device, (int)lds);
+    hipLaunchKernelGGL(narrow_conv3x3_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), lds, ctx.stream, a_split, lda, B, H, W, C,
+                       reinterpret_cast<const float4*>(w4), bias, N, out_nchw);
+    MAA_HIP(hipGetLastError());
+    return true;
 }
 void launch_pixel_shuffle2(const Ctx& ctx, const float* planes, int B, int H, int W, int C, float* out) {
     MAA_CHECK(C % 4 == 0, "pixel_shuffle2: channels must be a multiple of 4");

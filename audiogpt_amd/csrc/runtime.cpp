@@ -403,6 +403,26 @@ PackedW WeightStore::pack_conv_up2(const StateDict& sd, const std::string& wname
     return pw;
 }
 
+PackedW WeightStore::pack_narrow3x3(const StateDict& sd, const std::string& wname, const std::string& bname) {
+    PackedW pw;
+    const HostTensor& w = get(sd, wname);
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1];
+    if (Cout > 4 || Cin % 8 != 0 || w.numel() != (long long)Cout * Cin * 9 || bname.empty()) return pw;
+    std::vector<float> h((size_t)9 * Cin * 4, 0.f), hb(4, 0.f);
+    for (int t = 0; t < 9; ++t)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int co = 0; co < Cout; ++co)      // [tap][k = ci % 8][g = ci / 8][co]: a wave's lanes (g) read consecutive float4
+                h[(((size_t)t * 8 + (ci & 7)) * (Cin / 8) + (ci >> 3)) * 4 + co] = w.data[((size_t)co * Cin + ci) * 9 + t];
+    const HostTensor& b = get(sd, bname);
+    std::memcpy(hb.data(), b.data, sizeof(float) * Cout);
+    pw.w = upload(h);
+    pw.bias = upload(hb);
+    pw.K = 9 * Cin;
+    pw.N = Cout;
+    pw.Npad = 4;
+    return pw;
+}
+
 PackedW WeightStore::pack_concat(const StateDict& sd, const std::vector<std::string>& wnames,
                                  const std::vector<std::string>& bnames) {
     int N = 0, Cin = -1;

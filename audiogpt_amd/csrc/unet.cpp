@@ -67,7 +67,7 @@ struct UNet::Impl {
     std::vector<ConvW> convs;
     std::vector<std::vector<Layer>> input, output;
     std::vector<Layer> middle;
-    PackedW te0, te2, emb_all, out_conv;
+    PackedW te0, te2, emb_all, out_conv, out_narrow;
     float *out_g = nullptr, *out_b = nullptr;
     int emb_dim = 0, emb_total = 0;
     // cross-attention K/V cache: one [rows, 2*inner] buffer per transformer block
@@ -246,6 +246,7 @@ struct UNet::Impl {
         out_g = ws.vec(sd, "out.0.weight");
         out_b = ws.vec(sd, "out.0.bias");
         out_conv = ws.pack_conv(sd, "out.2.weight", "out.2.bias", 3, 3);
+        out_narrow = ws.pack_narrow3x3(sd, "out.2.weight", "out.2.bias");
         emb_all = ws.pack_concat(sd, emb_w, emb_b);
         MAA_CHECK(emb_all.N == emb_total, "emb_layers packing");
     }
@@ -501,6 +502,9 @@ struct UNet::Impl {
         T4 hn = alloc_t(ctx, B, H, W, mc);
         hn.split = split_for_gemm(ctx, mc);
         launch_groupnorm(ctx, h.p, mc, mc, nullptr, 0, 0, B, H * W, 32, out_g, out_b, 1e-5f, 1, hn.p, hn.split);
+        if (hn.split && ctx.tune.up2 &&
+            launch_narrow_conv3x3(ctx, hn.p, mc, B, H, W, mc, out_narrow.w, out_narrow.bias, cfg.out_channels, out_nchw))
+            return;      // (bf16x3: the 320 -> 4 convolution on its own kernel, straight to NCHW)
         T4 o = alloc_t(ctx, B, H, W, cfg.out_channels);
         ConvOpt co;
         co.KH = co.KW = 3;

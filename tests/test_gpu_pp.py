@@ -242,3 +242,22 @@ def test_upsample_conv_as_four_phase_convolutions(ctx, case):
         y_old = ctx.op_conv(x, w, b, pad=1, up=True).cpu()
         assert not any(k.startswith("igemm_pp_up2") for k in ctx.prof_end())
     check(f"pp_up2_vs_gather_{'x'.join(map(str, case))}", y, y_old, TOL)
+
+
+@pytest.mark.parametrize("case", [(16, 320, 4, 10, 78), (3, 320, 4, 10, 106), (1, 96, 3, 5, 7), (2, 640, 4, 3, 5)], ids=lambda c: "x".join(map(str, c)))
+def test_narrow_output_convolution(ctx, case):
+    """The UNet's last layer, conv3x3 320 -> 4 (openaimodel.py:693-697), on its own kernel in the bf16x3 mode (misc.hip
+    narrow_conv3x3_kernel: split32 rows in, fp32 FMAs, NCHW out) against conv2d in fp32 on the CPU: borders, sample boundaries, a
+    position count that is not a multiple of 16, channel counts beyond one pass of a wave (640) and N = 3."""
+    B, Cin, Cout, H, W = case
+    x = torch.randn(B, Cin, H, W, generator=g(W + Cin))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g(Cin)) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g(9))
+    with forced("", presplit=True):
+        ctx.prof_begin()
+        y = ctx.op_conv(x, w, b, pad=1).cpu()
+        rows = ctx.prof_end()
+        y1 = ctx.op_conv(x[:1], w, b, pad=1).cpu()
+    assert "narrow_conv3x3_kernel" in rows, rows.keys()
+    check(f"narrow_conv_{'x'.join(map(str, case))}", y, F.conv2d(x, w, b, padding=1), TOL)
+    assert torch.equal(y1, y[:1])
