@@ -75,13 +75,13 @@ class Context:
 
     def set_cfg_split(self, mode):
         """Classifier-free guidance inside `ddim_sample`: True -> the two halves of the UNet batch as two lanes (two branches of
-        the captured step graph), False -> one stream, None -> the default policy: two lanes unless three or more contexts are in flight
-        on the device (`set_concurrency`; one batch owning the GPU gains 4 %, with three in flight the extra lanes lose up to 24 %).  The results are the same bit for bit."""
+        the captured step graph), False -> one stream, None -> the default policy: two lanes unless the context has been told that three or more are in
+        flight on the device (`set_concurrency`; one batch owning the GPU gains 4 %, with three in flight the extra lanes lose up to 24 %).  The results are the same bit for bit."""
         L.check(self.lib.maa_ctx_set_cfg_split(self.h, -1 if mode is None else int(bool(mode))))
 
     def set_concurrency(self, n):
-        """The serving arrangement as a hint: how many contexts' launches the caller keeps in flight on this device (None: guess
-        from the number of live contexts).  >= 3: one stream per guided DDIM step and tiles by least total workgroup time; 1 or 2: this
+        """The serving arrangement as a hint: how many contexts' launches the caller keeps in flight on this device (None: not told,
+        treated as 1).  >= 3: one stream per guided DDIM step and tiles by least total workgroup time; 1 or 2: this
         context (nearly) owns the GPU (two CFG lanes, tiles by least launch time).  Bit-identical either way (include/maa.h)."""
         L.check(self.lib.maa_ctx_set_concurrency(self.h, -1 if n is None else int(n)))
 

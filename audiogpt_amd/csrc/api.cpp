@@ -132,7 +132,6 @@ int maa_ctx_create(int device_id, void* hip_stream, maa_ctx** out) {
             delete c;
             throw;
         }
-        maa::count_context(device_id, +1);
         *out = c;
     });
 }
@@ -144,7 +143,6 @@ int maa_ctx_destroy(maa_ctx* ctx) {
         if (ctx->owns_stream) (void)hipStreamDestroy(ctx->c.stream);
         if (ctx->c.zeros) (void)hipFree(ctx->c.zeros);
         delete ctx->c.prof;
-        maa::count_context(ctx->c.device, -1);
         delete ctx;
     });
 }
@@ -182,7 +180,7 @@ int maa_ctx_set_concurrency(maa_ctx* ctx, int n) {
     return guarded([&] {
         bind(ctx);
         MAA_CHECK(n >= -1 && n != 0, "concurrency: -1 (guess from the live contexts) or the number of contexts kept in flight (>= 1)");
-        if (ctx->c.kept_full() != ((n < 0 ? maa::live_contexts(ctx->c.device) : n) >= 3))
+        if (ctx->c.kept_full() != (n >= 3))
             ctx->c.ddim_graph.clear();      // the kept step graph was captured under the other arrangement's launches
         ctx->c.concurrency = n;
     });

@@ -97,9 +97,7 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n, int on) {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); safe from several launching threads
 void ensure_dynamic_lds(const void* kernel, int device, int bytes);
-int device_cu_count(int device);
-int live_contexts(int device);         // contexts created through maa_ctx_create and not yet destroyed, per device (runtime.cpp)
-void count_context(int device, int delta);      // multiProcessorCount, cached per device
+int device_cu_count(int device);      // multiProcessorCount, cached per device
 
 // grow-only device buffer owned by a context / model (growing synchronises the stream first: never inside a capture)
 struct DevSlab {
@@ -156,9 +154,10 @@ struct Ctx {
     // full from outside: a launch then costs the sum of its workgroups' time, not the rounds its own grid makes -- one stream per
     // guided DDIM step and igemm tiles by least total workgroup time; 1 or 2 = this context (nearly) owns the GPU: two CFG lanes
     // (+4 % with one context, +3.8 % with two, -24 % with three: profiles/r5/r5_call1_cfg_lanes_ab.txt, r5_call2_mixed_cfg_lanes_ab.txt),
-    // tiles by least launch time; -1 (default): guessed from the number of live contexts.  Every choice here is bit-identical.
+    // tiles by least launch time; -1 (default) = not told: treated as 1 -- an agent that loads three tools and runs one at a time has
+    // three idle contexts, so the number of live contexts says nothing about what is in flight.  Every choice here is bit-identical.
     int concurrency = -1;
-    bool kept_full() const { return (concurrency < 0 ? live_contexts(device) : concurrency) >= 3; }
+    bool kept_full() const { return concurrency >= 3; }
     int cfg_split = -1;       // -1: two lanes unless kept_full(); 0 / 1: maa_ctx_set_cfg_split
     bool split_cfg() const { return cfg_split < 0 ? !kept_full() : cfg_split != 0; }
     Tuning tune;

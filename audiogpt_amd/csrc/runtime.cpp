@@ -8,7 +8,6 @@
 
 #include <mutex>
 
-#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -241,14 +240,6 @@ void ensure_dynamic_lds(const void* kernel, int device, int bytes) {
     if (have >= bytes) return;
     MAA_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     have = bytes;
-}
-
-namespace {
-std::atomic<int> g_live_contexts[64];
-}
-int live_contexts(int device) { return device >= 0 && device < 64 ? g_live_contexts[device].load() : 1; }
-void count_context(int device, int delta) {
-    if (device >= 0 && device < 64) g_live_contexts[device].fetch_add(delta);
 }
 
 int device_cu_count(int device) {

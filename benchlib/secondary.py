@@ -209,10 +209,14 @@ def run_t2a_variant(dev, precision, vocoder_cfg, label, cpu_parts=None, steps=6,
            "config": {"workload": label, "prompts_per_gpu": n, "ddim_steps": S, "batches_in_flight": inflight,
                       "audio_seconds_per_step": audio_s},
            "one_batch_in_flight": {"value": audio_s / one, "ms_per_step": 1e3 * one}}
-    if roofline:
+    if roofline:      # ONE eager stream: the context is told it owns the GPU (tiles by launch time), as in bench.main's roofline pass
+        pipes[0].ctx.set_concurrency(1)
+        pipes[0].ctx.set_cfg_split(False)
         pipes[0].ctx.prof_begin()
         pipes[0].generate(x_T, c, uc, CFG_SCALE, S, use_graph=False)
         res["roofline"] = roofline_of(pipes[0].ctx.prof_end(), precision)
+        pipes[0].ctx.set_concurrency(inflight)
+        pipes[0].ctx.set_cfg_split(inflight == 1)
     if parity_against in ("f32", "bf16x3", "bf16"):
         ref = MakeAnAudio(dev, vocoder_cfg=vocoder_cfg, precision=parity_against)
         wav_r, spec_r, _ = ref.generate(x_T, c, uc, CFG_SCALE, S)

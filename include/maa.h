@@ -63,10 +63,9 @@ int maa_ctx_set_precision(maa_ctx* ctx, int mode);
  * unconditional and the conditional half of that batch are independent trajectories until the combine, and the library runs
  * them as two lanes -- two branches of the captured step graph, each half on its own stream and workspace -- because one batch
  * of 8 prompts leaves much of the chip idle.  Bit-identical to the one-stream form (every kernel is batch-invariant).
- *   1 two lanes, 0 one stream, -1 the default policy: two lanes unless the chip is kept full from outside (three or more contexts
- * in flight, maa_ctx_set_concurrency below; measured +4 % for one batch owning the GPU, +3.8 % with two contexts, -24 % with
- * three, profiles/r5/r5_call1_cfg_lanes_ab.txt) -- a server that keeps several batches in flight on several contexts gets one
- * stream per context without asking. */
+ *   1 two lanes, 0 one stream, -1 the default policy: two lanes unless the caller has said that the chip is kept full from
+ * outside (maa_ctx_set_concurrency(ctx, n >= 3) below; measured +4 % for one batch owning the GPU, +3.8 % with two contexts in
+ * flight, -24 % with three, profiles/r5/r5_call1_cfg_lanes_ab.txt). */
 int maa_ctx_set_cfg_split(maa_ctx* ctx, int mode);
 /* The serving arrangement, as a hint (no counterpart in the reference, which runs one request at a time): n = how many contexts'
  * launches the caller keeps in flight on this device.  n >= 3: the chip is kept full from outside, so a launch costs the sum of
@@ -74,10 +73,12 @@ int maa_ctx_set_cfg_split(maa_ctx* ctx, int mode);
  * concurrent lanes lose 24 %) and the short-K contractions take the tile with the least total workgroup time (128 x 64 / 128 x 128
  * where one launch alone would take 64 x 64: +0.9 % with three batches in flight, -7 % for a batch alone,
  * profiles/r6_call6_tile_mode_ab.txt).  n = 1 or 2: this context (nearly) owns the GPU -- two CFG lanes (+4 % / +3.8 %), tiles by
- * least launch time.  -1 (default): guessed from the number of contexts alive on the device.  Every choice is bit-identical; a
- * kept DDIM step graph is dropped when the arrangement changes.  maa_ctx_set_cfg_split overrides the lanes part. */
+ * least launch time.  -1 (default) = not told, treated as 1: a server that keeps three or more batches in flight on as many
+ * contexts SHOULD call this (or maa_ctx_set_cfg_split(ctx, 0)) -- left at the default it runs six CFG lanes and loses 24 %.  Every
+ * choice is bit-identical; a kept DDIM step graph is dropped when the arrangement changes.  maa_ctx_set_cfg_split overrides the
+ * lanes part. */
 int maa_ctx_set_concurrency(maa_ctx* ctx, int n);
-/* The test / A-B knobs of the environment (MAA_PP, MAA_PP1, MAA_PP_S, MAA_PP_TILE_MAJOR, MAA_DMA2, MAA_NO_DMA, MAA_HALO,
+/* The test / A-B knobs of the environment (MAA_PP, MAA_PP1, MAA_PP_S, MAA_PP_TILE_MAJOR, MAA_UP2, MAA_DMA2, MAA_NO_DMA, MAA_HALO,
  * MAA_OP_PRESPLIT, MAA_GN_TWO_PASS) are parsed in one place, when a context is created; this parses them again
  * (and drops the step graph the sampler keeps).  A malformed MAA_DMA2 value fails here (and in maa_ctx_create) with a message
  * naming the variable.  For tests and A/B runs; a -DMAA_NO_TUNING build ignores the environment. */

@@ -20,7 +20,7 @@ q = "select %s, %s, %s count(*), sum(%s) from counters_collection group by %s, %
 rows = list(cur.execute(q))
 agg = {}
 for k, c, g, n, v in rows:
-    k = k.replace("maa::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:50]
+    k = k.replace("maa::(anonymous namespace)::", "").replace("void ", "").split("(")[0][:64]
     agg.setdefault((k, g), {})[c] = (n, v)
 def key(item):
     d = item[1]
@@ -30,4 +30,4 @@ def key(item):
     return 0
 for (k, g), d in sorted(agg.items(), key=key)[:top]:
     n = max(v[0] for v in d.values())
-    print("%-50s grid %-9s launches %5d  " % (k, g, n) + "  ".join("%s=%.4g" % (c, v[1]) for c, v in sorted(d.items())))
+    print("%-64s grid %-9s launches %5d  " % (k, g, n) + "  ".join("%s=%.4g" % (c, v[1]) for c, v in sorted(d.items())))

@@ -42,6 +42,19 @@ LABELS = {  # bench.py / maa_prof label -> (rocprof kernel prefixes, prefix whos
     "igemm_f32<128x64>": (["igemm_f32_kernel<128, 64"], "igemm_f32_kernel<128, 64"),
     "igemm_f32<128x128>": (["igemm_f32_kernel<128, 128"], "igemm_f32_kernel<128, 128"),
 }
+LABELS["igemm_pp_up2_bf16x3<256x160>"] = (["UP2:igemm_pp_kernel<1, 5, 4, 1"], "UP2:igemm_pp_kernel<1, 5, 4, 1")
+LABELS["igemm_pp_up2_bf16x3<256x128>"] = (["UP2:igemm_pp_kernel<2, 2, 2, 2"], "UP2:igemm_pp_kernel<2, 2, 2, 2")
+
+
+def match(name, prefix):
+    """rocprof kernel name against a label's prefix; the UP2 instantiations of igemm_pp_kernel (last template argument true: the
+    four-phase upsample convolution, round 6) are labels of their own ("UP2:" prefixes) and never count as the plain engine's."""
+    up2 = name.startswith("igemm_pp_kernel<") and name.rstrip().rstrip("(").endswith(", true>")
+    if prefix.startswith("UP2:"):
+        return up2 and name.startswith(prefix[4:])
+    return name.startswith(prefix) and not up2
+
+
 rows = {"FETCH_SIZE": {}, "WRITE_SIZE": {}, "SQ_VALU_MFMA_BUSY_CYCLES": {}, "GRBM_GUI_ACTIVE": {}}   # counter -> kernel name -> (launches, sum)
 section = None
 for line in open(path):
@@ -61,9 +74,9 @@ for label, (prefixes, count_prefix) in LABELS.items():
     tot, n = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}, 0
     for c in tot:
         for name, (ln, kb) in rows[c].items():
-            if any(name.startswith(p) for p in prefixes):
+            if any(match(name, p) for p in prefixes):
                 tot[c] += kb
-            if c == "FETCH_SIZE" and name.startswith(count_prefix):
+            if c == "FETCH_SIZE" and match(name, count_prefix):
                 n += ln
     if n:
         kernels[label] = {"hbm_bytes_per_launch": (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0 / n,
@@ -71,8 +84,8 @@ for label, (prefixes, count_prefix) in LABELS.items():
                           "launches_per_ddim_step": n / float(steps)}
         # matrix-pipe occupancy of the GEMM launch itself (the reduce launch has no MFMAs): SQ_VALU_MFMA_BUSY_CYCLES counts
         # busy cycles summed over the chip's 1024 SIMDs, GRBM_GUI_ACTIVE the kernel's cycles summed over the 8 XCDs
-        busy = sum(v for name, (ln, v) in rows["SQ_VALU_MFMA_BUSY_CYCLES"].items() if name.startswith(count_prefix))
-        act = sum(v for name, (ln, v) in rows["GRBM_GUI_ACTIVE"].items() if name.startswith(count_prefix))
+        busy = sum(v for name, (ln, v) in rows["SQ_VALU_MFMA_BUSY_CYCLES"].items() if match(name, count_prefix))
+        act = sum(v for name, (ln, v) in rows["GRBM_GUI_ACTIVE"].items() if match(name, count_prefix))
         if busy and act:
             kernels[label]["mfma_busy"] = busy / (act / 8.0 * 1024.0)
 from audiogpt_amd.build import _source_hash  # noqa: E402
