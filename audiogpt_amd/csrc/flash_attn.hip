@@ -61,6 +61,9 @@ struct Frag {      // 8 bf16 = 4 dwords, bit-castable to the MFMA operand type
 __device__ __forceinline__ bf16x8 as_bf16x8(const Frag& f) { return __builtin_bit_cast(bf16x8, f); }
 
 // (capping the d = 40 kernel at 128 VGPRs -- four workgroups per CU -- spills and is 20 % slower: DESIGN.md 3.3)
+// (round 6: five-wave workgroups of 160 query rows where that takes fewer waves -- 780 tokens: 5 x 5 waves instead of 7 x 4 with
+// three of them empty, each K / V tile staged for five waves -- measured 0.6 % SLOWER end to end, two workgroups per CU instead of
+// three: profiles/r6_call12_flash5_ab.txt)
 template <int DH, int TERMS>
 __global__ __launch_bounds__(NT, 1) void flash_attn_kernel(const FlashArgs a) {
     constexpr int DK = (DH + 15) / 16 * 16;      // head dim padded to the MFMA k-step
