@@ -17,7 +17,7 @@ for set in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE" "SQ_VALU_MF
   n=$(echo $set | cut -d_ -f1-2 | tr -d ' ')
   timeout 300 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmc_${tag}_$n -o pmc -- python scripts/pmc_workload.py $prec $STEPS > gpurun_out/pmc_${tag}_$n.log 2>&1
   echo "== $(echo $set | cut -d' ' -f1)  [$set]  ($STEPS DDIM steps, 8 latents + CFG, $prec)" >> gpurun_out/${tag}_${prec}_pmc_fetch_write.txt
-  python scripts/pmc_summary.py gpurun_out/pmc_${tag}_$n/pmc_results.db 30 | grep -v "^# columns" >> gpurun_out/${tag}_${prec}_pmc_fetch_write.txt 2>&1
+  python scripts/pmc_summary.py gpurun_out/pmc_${tag}_$n/pmc_results.db 60 | grep -v "^# columns" >> gpurun_out/${tag}_${prec}_pmc_fetch_write.txt 2>&1
   rm -rf gpurun_out/pmc_${tag}_$n gpurun_out/pmc_${tag}_$n.log
 done
 python scripts/pmc_traffic_json.py gpurun_out/${tag}_${prec}_pmc_fetch_write.txt $prec $STEPS profiles/pmc_traffic.json && cp profiles/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.json

@@ -18,13 +18,13 @@ for wl in ${WORKLOADS:-hifigan64 mixed}; do
     n=$(echo $set | cut -d_ -f1)
     timeout 600 rocprofv3 --kernel-trace --pmc $set -d gpurun_out/pmc_${tag}_${wl}_$n -o pmc -- python bench.py --workload $wl $pmc_args --precision $prec --no-roofline --no-cpu-baseline > gpurun_out/pmc_${tag}_${wl}_$n.log 2>&1
     echo "== $set" >> $out
-    python scripts/pmc_summary.py gpurun_out/pmc_${tag}_${wl}_$n/pmc_results.db 24 | grep -v "^# columns" >> $out 2>&1
+    python scripts/pmc_summary.py gpurun_out/pmc_${tag}_${wl}_$n/pmc_results.db 80 | grep -v "^# columns" >> $out 2>&1
     rm -rf gpurun_out/pmc_${tag}_${wl}_$n
   done
   # third pass: matrix-pipe occupancy; then the per-launch table bench.py's `secondary` rooflines read (profiles/pmc_traffic.json)
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d gpurun_out/pmc_${tag}_${wl}_SQ -o pmc -- python bench.py --workload $wl $pmc_args --precision $prec --no-roofline --no-cpu-baseline > gpurun_out/pmc_${tag}_${wl}_SQ.log 2>&1
   echo "== SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" >> $out
-  python scripts/pmc_summary.py gpurun_out/pmc_${tag}_${wl}_SQ/pmc_results.db 24 | grep -v "^# columns" >> $out 2>&1
+  python scripts/pmc_summary.py gpurun_out/pmc_${tag}_${wl}_SQ/pmc_results.db 80 | grep -v "^# columns" >> $out 2>&1
   rm -rf gpurun_out/pmc_${tag}_${wl}_SQ
   if [ $wl = mixed ]; then units=4; else units=1; fi
   python scripts/pmc_traffic_json.py $out $prec $units profiles/pmc_traffic.json --section $wl && cp profiles/pmc_traffic.json gpurun_out/${tag}_pmc_traffic.json
