@@ -20,7 +20,7 @@ def _bench(tmp_path, name, extra, port):
     out = str(tmp_path / (name + ".json"))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--ddim-steps", "5",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--ddim-steps", "5",
            "--no-cpu-baseline", "--no-roofline", "--no-secondary", "--no-one-batch", "--json-out", out] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
