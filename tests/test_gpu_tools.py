@@ -10,7 +10,7 @@ import torch
 
 from audiogpt_amd import config as C
 from audiogpt_amd import weights as WT
-from tests.util import check, record, rel_err
+from tests.util import check, oracle_cached, record, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -44,9 +44,6 @@ def _cached(kind, precision="bf16x3"):
                 "Inpaint": lambda: Inpaint("cuda:0", precision=precision)}[kind]
         _CACHE[key] = make()
     return _CACHE[key]
-
-
-_ORACLE_T2A = {}      # the CPU oracle chain of the T2A test does not depend on the precision under test: computed once
 
 
 # ------------------------------------------------------------------------------------------------ sampler + model object
@@ -159,16 +156,17 @@ def test_T2A_txt2audio_matches_oracle_chain(precision):
     c = model.get_learned_conditioning([text]).cpu()
     uc = model.get_learned_conditioning([""]).cpu()
     x_T = torch.from_numpy(np.random.RandomState(55).randn(1, 4, 10, 78)).float()
-    usd = WT.make_unet_state_dict(C.UNET_T2A, seed=0)
-    vsd = WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1)
-    gsd = WT.make_vocoder_state_dict(C.BIGVGAN_16K, seed=3)
-    key = (c.numpy().tobytes(), uc.numpy().tobytes(), S)
-    if key not in _ORACLE_T2A:
+
+    def chain():
+        usd = WT.make_unet_state_dict(C.UNET_T2A, seed=0)
+        vsd = WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1)
+        gsd = WT.make_vocoder_state_dict(C.BIGVGAN_16K, seed=3)
         with torch.no_grad():
             z = O_ddim.ddim_sample(lambda x, t, cc: O_unet.unet_forward(usd, C.UNET_T2A, x, t, cc), _ac(C.LDM_T2A), S, x_T, c, uc, 1.5)
             spec = torch.clamp((O_vae.decode_first_stage(vsd, C.VAE_DDCONFIG, z, 1.0) + 1.0) / 2.0, 0.0, 1.0)[:, 0]
-            _ORACLE_T2A[key] = O_voc.bigvgan_forward(O_voc.fold_weight_norm(gsd), C.BIGVGAN_16K, spec)[0, 0].numpy()
-    wav_ref = _ORACLE_T2A[key]
+            return {"wav": O_voc.bigvgan_forward(O_voc.fold_weight_norm(gsd), C.BIGVGAN_16K, spec)[0, 0]}
+    # (the oracle's answer does not depend on the precision under test: one cache entry, tests/util.oracle_cached)
+    wav_ref = oracle_cached("tools_T2A_txt2audio_s%d" % S, dict(c=c, uc=uc, x_T=x_T, S=S, scale=1.5, seeds=(0, 1, 3), cfg="UNET_T2A/BIGVGAN_16K"), chain)["wav"]
     rms = _rms(wav, wav_ref)
     record(f"tools_{precision}_T2A.txt2audio_s{S}", wav_rms=rms, tol=1e-4)
     assert rms <= 1e-4, rms
@@ -203,13 +201,16 @@ def test_I2A_img2audio_matches_oracle_chain():
     c = model.cond_stage_model.forward_img(model.cond_stage_model.preprocess(image).unsqueeze(0)).cpu()
     assert c.shape == (1, 1, 1024) and uc.shape == (1, 1, 1024)
     x_T = torch.from_numpy(np.random.RandomState(55).randn(1, 4, 10, 78)).float()
-    usd = WT.make_unet_state_dict(C.UNET_I2A, seed=4)
-    vsd = WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1)
-    gsd = WT.make_vocoder_state_dict(C.BIGVGAN_16K, seed=3)
-    with torch.no_grad():
-        z = O_ddim.ddim_sample(lambda x, t, cc: O_unet.unet_forward(usd, C.UNET_I2A, x, t, cc), _ac(C.LDM_I2A), S, x_T, c, uc, 3.0)
-        spec = torch.clamp((O_vae.decode_first_stage(vsd, C.VAE_DDCONFIG, z, 1.0) + 1.0) / 2.0, 0.0, 1.0)[:, 0]
-        wav_ref = O_voc.bigvgan_forward(O_voc.fold_weight_norm(gsd), C.BIGVGAN_16K, spec)[0, 0].numpy()
+
+    def chain():
+        usd = WT.make_unet_state_dict(C.UNET_I2A, seed=4)
+        vsd = WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1)
+        gsd = WT.make_vocoder_state_dict(C.BIGVGAN_16K, seed=3)
+        with torch.no_grad():
+            z = O_ddim.ddim_sample(lambda x, t, cc: O_unet.unet_forward(usd, C.UNET_I2A, x, t, cc), _ac(C.LDM_I2A), S, x_T, c, uc, 3.0)
+            spec = torch.clamp((O_vae.decode_first_stage(vsd, C.VAE_DDCONFIG, z, 1.0) + 1.0) / 2.0, 0.0, 1.0)[:, 0]
+            return {"wav": O_voc.bigvgan_forward(O_voc.fold_weight_norm(gsd), C.BIGVGAN_16K, spec)[0, 0]}
+    wav_ref = oracle_cached("tools_I2A_img2audio_s%d" % S, dict(c=c, uc=uc, x_T=x_T, S=S, scale=3.0, seeds=(4, 1, 3), cfg="UNET_I2A/BIGVGAN_16K"), chain)["wav"]
     rms = _rms(wav, wav_ref)
     record("tools_bf16x3_I2A.img2audio_s4", wav_rms=rms, tol=1e-4)
     assert rms <= 1e-4, rms
@@ -235,22 +236,27 @@ def test_Inpaint_inference_mel_matches_oracle_chain():
     torch.manual_seed(123)
     noise = torch.randn((1, 4, 10, 106), device="cuda").cpu()
     x_T = torch.randn((1, 4, 10, 106), device="cuda").cpu()
-    usd = WT.make_unet_state_dict(C.UNET_INPAINT, seed=5)
-    vsd = WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1)
-    gsd = WT.make_vocoder_state_dict(C.BIGVGAN_16K, seed=3)
     mel = torch.from_numpy(mel_in[:, :848])[None, None]
     msk = torch.from_numpy(np.pad(mask, ((0, 0), (0, 848 - 700))))[None, None]
     masked = (1 - msk) * mel
-    with torch.no_grad():
-        mean, logvar = O_vae.encode_moments(vsd, C.VAE_DDCONFIG, masked * 2 - 1)
-        zc = O_vae.posterior_sample(mean, logvar, noise)
-        cc = torch.nn.functional.interpolate(msk * 2 - 1, size=zc.shape[-2:])
-        cond = torch.cat((zc, cc), dim=1)
-        z = O_ddim.ddim_sample(lambda x, t, c_: O_unet.unet_forward(usd, C.UNET_INPAINT, torch.cat([x, c_], 1), t, None),
-                               _ac(C.LDM_INPAINT), S, x_T, cond)
-        pred = torch.clamp((O_vae.decode_first_stage(vsd, C.VAE_DDCONFIG, z, 1.0) + 1.0) / 2.0, 0.0, 1.0)
-        ref_mel = ((1 - msk) * mel + msk * pred)[0, 0]
-        wav_ref = O_voc.bigvgan_forward(O_voc.fold_weight_norm(gsd), C.BIGVGAN_16K, ref_mel[None])[0, 0].numpy()
+    def chain():
+        usd = WT.make_unet_state_dict(C.UNET_INPAINT, seed=5)
+        vsd = WT.make_vae_state_dict(C.VAE_DDCONFIG, seed=1)
+        gsd = WT.make_vocoder_state_dict(C.BIGVGAN_16K, seed=3)
+        with torch.no_grad():
+            mean, logvar = O_vae.encode_moments(vsd, C.VAE_DDCONFIG, masked * 2 - 1)
+            zc = O_vae.posterior_sample(mean, logvar, noise)
+            cc = torch.nn.functional.interpolate(msk * 2 - 1, size=zc.shape[-2:])
+            cond = torch.cat((zc, cc), dim=1)
+            z = O_ddim.ddim_sample(lambda x, t, c_: O_unet.unet_forward(usd, C.UNET_INPAINT, torch.cat([x, c_], 1), t, None),
+                                   _ac(C.LDM_INPAINT), S, x_T, cond)
+            pred = torch.clamp((O_vae.decode_first_stage(vsd, C.VAE_DDCONFIG, z, 1.0) + 1.0) / 2.0, 0.0, 1.0)
+            ref = ((1 - msk) * mel + msk * pred)[0, 0]
+            return {"mel": ref, "wav": O_voc.bigvgan_forward(O_voc.fold_weight_norm(gsd), C.BIGVGAN_16K, ref[None])[0, 0]}
+    # (noise / x_T are the device generator's draws: part of the key -- another torch build's stream simply misses the cache)
+    ref = oracle_cached("tools_Inpaint_inference_mel_s%d" % S, dict(mel=mel, msk=msk, noise=noise, x_T=x_T, S=S, seeds=(5, 1, 3),
+                                                                    cfg="UNET_INPAINT/BIGVGAN_16K"), chain)
+    ref_mel, wav_ref = torch.from_numpy(ref["mel"]), ref["wav"]
     l1 = float(np.abs(inpainted.astype(np.float64) - ref_mel.numpy().astype(np.float64)).mean())
     rms = _rms(wav, wav_ref)
     record("tools_bf16x3_Inpaint.inference_mel_s4", mel_l1=l1, wav_rms=rms, tol=1e-4)
