@@ -62,7 +62,8 @@ class maa_vocoder_config(C.Structure):
                 ("n_kernels", C.c_int), ("resblock_kernel_sizes", C.c_int * 8),
                 ("n_dilations", C.c_int), ("resblock_dilation_sizes", (C.c_int * 8) * 8),
                 ("snake_beta", C.c_int), ("snake_logscale", C.c_int),
-                ("use_pitch_embed", C.c_int), ("sampling_rate", C.c_int), ("harmonic_num", C.c_int)]
+                ("use_pitch_embed", C.c_int), ("sampling_rate", C.c_int), ("harmonic_num", C.c_int),
+                ("resblock", C.c_int)]
 
 
 class maa_diffnet_config(C.Structure):

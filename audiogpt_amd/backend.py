@@ -376,6 +376,20 @@ class UNet:
                 return x, out[0], out[1]
         return x
 
+    def ddim_update(self, x, eps_uncond, eps_cond, scale, a_t, a_prev, sigma_t, sqrt_one_minus_at):
+        """p_sample_ddim's elementwise tail for ONE step (ddim.py:199, 210-225 without the noise term) through
+        `maa_ddim_update`: e = eu + scale (ec - eu) (eps_cond None: e = eps_uncond), returns (x_prev, pred_x0).  Used by the
+        sampler's host-side loop (score correctors / callbacks); the device loop has its own fused form."""
+        dev = self.ctx.device
+        x, eu = _f32(x, dev), _f32(eps_uncond, dev)
+        ec = None if eps_cond is None else _f32(eps_cond, dev)
+        coef = torch.tensor([a_t, a_prev, sigma_t, sqrt_one_minus_at], dtype=torch.float32).to(dev)
+        x_prev, pred = torch.empty_like(x), torch.empty_like(x)
+        with self.ctx.lock:
+            L.check(self.ctx.lib.maa_ddim_update(self.ctx.h, L.dptr(x), L.dptr(eu), L.dptr(ec) if ec is not None else None,
+                                                 float(scale), L.dptr(coef), x.numel(), L.dptr(x_prev), L.dptr(pred)))
+        return x_prev, pred
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.maa_unet_destroy(self.h)
@@ -466,6 +480,9 @@ class Vocoder:
         c.use_pitch_embed = int(self.nsf)
         c.sampling_rate = int(cfg.get("sampling_rate", 0))
         c.harmonic_num = self.harmonics = 8 if self.nsf else 0            # hifigan.py:112
+        c.resblock = int(cfg.get("resblock", "1"))                        # hifigan.py:119: '1' -> ResBlock1, else ResBlock2
+        if c.resblock != 1:
+            c.resblock = 2
         arr, n, keep = L.tensor_list(state_dict)
         h = C.c_void_p()
         with ctx.lock:

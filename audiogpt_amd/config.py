@@ -79,6 +79,13 @@ HIFIGAN_16K = dict(           # MAA/vocoder/logs/hifi_0127/args.yml
 HIFIGAN_NS_512 = dict(HIFIGAN_16K, sampling_rate=22050)                    # egs_bases/tts/vocoder/hifigan.yaml
 HIFIGAN_NS_128 = dict(HIFIGAN_16K, sampling_rate=22050, upsample_initial_channel=128)  # configs/tts/hifigan.yaml
 
+# The generators' other residual block (`resblock: "2"`: ResBlock2, hifigan.py:70-91 / modules.py:62-83; AMPBlock2,
+# bigvgan/models.py:90-132): no shipped config selects it -- these are HiFi-GAN's published V3 shapes (hop 256), and
+# the same with BigVGAN's plain `snake` activation (activations.py:8-59), which BIGVGAN_16K does not exercise either.
+HIFIGAN_RB2 = dict(HIFIGAN_16K, upsample_initial_channel=256, upsample_rates=(8, 8, 4), upsample_kernel_sizes=(16, 16, 8),
+                   resblock="2", resblock_kernel_sizes=(3, 5, 7), resblock_dilation_sizes=((1, 2), (2, 6), (3, 12)))
+BIGVGAN_RB2 = dict(HIFIGAN_RB2, kind="bigvgan", activation="snake", snake_logscale=False)
+
 # NSF (f0-conditioned) generator of the singing tools: checkpoints/0109_hifigan_bigpopcs_hop128 is not shipped, so the
 # rates are the hop-128 / 24 kHz factorisation assumed here (egs_bases/svs/popcs_ds_beta6.yaml:6-7,54-55,70); used by the
 # oracle groundwork for SURVEY 8f/N1 only.

@@ -1,8 +1,8 @@
 // HiFi-GAN / BigVGAN MRF generator executor on channels-last sequences [B, L, C].
 //
-// Mirrors: NeuralSeq/modules/hifigan/hifigan.py:104-178 (HifiGanGenerator, f0=None), :30-67 ResBlock1
+// Mirrors: NeuralSeq/modules/hifigan/hifigan.py:104-178 (HifiGanGenerator, f0=None), :30-67 ResBlock1, :70-91 ResBlock2
 //          text_to_audio/Make_An_Audio/vocoder/hifigan/modules.py:86-136 (same graph)
-//          text_to_audio/Make_An_Audio/vocoder/bigvgan/models.py:30-81,133-203 (AMPBlock1, BigVGAN)
+//          text_to_audio/Make_An_Audio/vocoder/bigvgan/models.py:30-81,133-203 (AMPBlock1, BigVGAN), :90-132 AMPBlock2
 // What is fused instead of launched (same maths):
 //   * every leaky-ReLU is applied while the following conv stages its A tile
 //   * `xt + x` and the MRF mean (rb0+rb1+rb2)/3 are igemm epilogues (out_scale 1/3, accumulate)
@@ -23,8 +23,8 @@ struct ConvK {
     int k = 1, dil = 1;
 };
 struct ResBlockW {
-    std::vector<ConvK> c1, c2;
-    // BigVGAN: per-activation snake parameters (device), 2 per (c1, c2) pair
+    std::vector<ConvK> c1, c2;      // resblock "2" (ResBlock2 / AMPBlock2): c2 is empty, c1 holds `convs.{m}`
+    // BigVGAN: per-activation snake parameters (device), 2 per (c1, c2) pair (one per conv of an AMPBlock2)
     std::vector<float*> alpha, inv_beta;
 };
 struct UpW {
@@ -140,6 +140,18 @@ struct Vocoder::Impl {
                     a.k = b.k = cfg.resblock_kernel_sizes[j];
                     a.dil = cfg.resblock_dilation_sizes[j][m];
                     b.dil = 1;
+                    if (cfg.resblock == 2) {          // hifigan.py:74-80 / bigvgan models.py:95-117: `convs`, `activations`
+                        a.w = ws.pack_conv(sd, p + "convs." + std::to_string(m) + ".weight",
+                                           p + "convs." + std::to_string(m) + ".bias", 1, a.k);
+                        rb.c1.push_back(a);
+                        if (big) {
+                            float *al, *ib;
+                            snake_params(sd, p + "activations." + std::to_string(m) + ".", &al, &ib);
+                            rb.alpha.push_back(al);
+                            rb.inv_beta.push_back(ib);
+                        }
+                        continue;
+                    }
                     a.w = ws.pack_conv(sd, p + "convs1." + std::to_string(m) + ".weight",
                                        p + "convs1." + std::to_string(m) + ".bias", 1, a.k);
                     b.w = ws.pack_conv(sd, p + "convs2." + std::to_string(m) + ".weight",
@@ -323,6 +335,32 @@ struct Vocoder::Impl {
                 }
                 for (size_t mth = 0; mth < rb.c1.size(); ++mth) {
                     const bool last = mth + 1 == rb.c1.size();
+                    if (cfg.resblock == 2) {
+                        // xt = c(act(x)); x = xt + x                      (hifigan.py:83-88 / bigvgan models.py:122-128)
+                        if (presplit) {
+                            if (last) {
+                                conv1d_split(ctx, cur_s, rb.c1[mth], 0.f, cur.p, inv_n, j > 0, xs, nullptr, 1.f);
+                            } else {
+                                T4& dst = (cur.p == bufA.p) ? bufB : bufA;
+                                T4& dst_s = (cur_s.p == sA.p) ? sB : sA;
+                                conv1d_split(ctx, cur_s, rb.c1[mth], 0.f, cur.p, 1.f, 0, dst, dst_s.p, 0.1f);
+                                cur = dst;
+                                cur_s = dst_s;
+                            }
+                            continue;
+                        }
+                        if (big) launch_snake_aa(ctx, cur.p, B, L, u.cout, rb.inv_beta[mth], rb.alpha[mth], act.p);
+                        const T4& in1 = big ? act : cur;
+                        const float lk1 = big ? 0.f : 0.1f;
+                        if (last) {
+                            conv1d(ctx, in1, rb.c1[mth], lk1, cur.p, inv_n, j > 0, xs);
+                        } else {
+                            T4& dst = (cur.p == bufA.p) ? bufB : bufA;
+                            conv1d(ctx, in1, rb.c1[mth], lk1, cur.p, 1.f, 0, dst);
+                            cur = dst;
+                        }
+                        continue;
+                    }
                     // xt = c1(act(x)); xt = c2(act(xt)); x = xt + x      (hifigan.py:54-61 / bigvgan models.py:72-81)
                     if (presplit) {
                         conv1d_split(ctx, cur_s, rb.c1[mth], 0.1f, nullptr, 1.f, 0, t1, nullptr, 1.f);      // t1 = split(leaky(c1(.)))
@@ -391,6 +429,7 @@ struct Vocoder::Impl {
 };
 
 Vocoder::Vocoder(const maa_vocoder_config& cfg, const StateDict& sd, int precision) : impl_(new Impl(precision)) {
+    MAA_CHECK(cfg.resblock >= 0 && cfg.resblock <= 2, "maa_vocoder_config.resblock is 1 or 2 (0 = 1)");
     impl_->cfg = cfg;
     impl_->build(sd);
 }

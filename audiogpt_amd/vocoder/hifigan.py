@@ -46,8 +46,6 @@ def _cfg_from_h(h, kind="hifigan"):
                resblock=str(g("resblock", "1")), resblock_kernel_sizes=tuple(g("resblock_kernel_sizes")),
                resblock_dilation_sizes=tuple(tuple(d) for d in g("resblock_dilation_sizes")),
                sampling_rate=g("sampling_rate", g("audio_sample_rate", 22050)))
-    if cfg["resblock"] != "1":
-        raise NotImplementedError("only resblock '1' (the shipped configs) is implemented")
     if g("use_pitch_embed", False):
         cfg["use_pitch_embed"] = True
         cfg["sampling_rate"] = g("audio_sample_rate", cfg["sampling_rate"])

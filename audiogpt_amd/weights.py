@@ -264,6 +264,13 @@ def make_vocoder_state_dict(cfg, seed=2):
     big = cfg["kind"] == "bigvgan"
     _wn(sd, g, "conv_pre", (uic, cfg["num_mels"], 7))
     sd["conv_pre.bias"] = g.bias(uic)
+
+    def snake_param(n):
+        # activations.py:29-34,83-90: log-scale parameters start at 0, linear ones at 1 (1 / alpha must stay bounded)
+        if cfg.get("snake_logscale", False):
+            return g.normal((n,), 0.3)
+        return (1.0 + g.normal((n,), 0.2)).clamp(min=0.4)
+
     nk = len(cfg["resblock_kernel_sizes"])
     ch = uic
     for i, (u, k) in enumerate(zip(cfg["upsample_rates"], cfg["upsample_kernel_sizes"])):
@@ -275,20 +282,25 @@ def make_vocoder_state_dict(cfg, seed=2):
         ch = cout
         for j, (rk, rd) in enumerate(zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"])):
             p = f"resblocks.{i * nk + j}."
+            rb2 = str(cfg.get("resblock", "1")) != "1"          # ResBlock2 / AMPBlock2: one conv (and one activation) per dilation
             for m in range(len(rd)):
+                if rb2:
+                    _wn(sd, g, p + f"convs.{m}", (ch, ch, rk), gain=0.6)
+                    sd[p + f"convs.{m}.bias"] = g.bias(ch)
+                    continue
                 _wn(sd, g, p + f"convs1.{m}", (ch, ch, rk), gain=1.0)
                 sd[p + f"convs1.{m}.bias"] = g.bias(ch)
                 _wn(sd, g, p + f"convs2.{m}", (ch, ch, rk), gain=0.4)
                 sd[p + f"convs2.{m}.bias"] = g.bias(ch)
             if big:
-                for m in range(2 * len(rd)):
-                    sd[p + f"activations.{m}.act.alpha"] = g.normal((ch,), 0.3)
+                for m in range((1 if rb2 else 2) * len(rd)):
+                    sd[p + f"activations.{m}.act.alpha"] = snake_param(ch)
                     if cfg["activation"] == "snakebeta":
-                        sd[p + f"activations.{m}.act.beta"] = g.normal((ch,), 0.3)
+                        sd[p + f"activations.{m}.act.beta"] = snake_param(ch)
     if big:
-        sd["activation_post.act.alpha"] = g.normal((ch,), 0.3)
+        sd["activation_post.act.alpha"] = snake_param(ch)
         if cfg["activation"] == "snakebeta":
-            sd["activation_post.act.beta"] = g.normal((ch,), 0.3)
+            sd["activation_post.act.beta"] = snake_param(ch)
     _wn(sd, g, "conv_post", (1, ch, 7), gain=0.3)
     sd["conv_post.bias"] = g.bias(1)
     if cfg.get("use_pitch_embed"):

@@ -148,7 +148,8 @@ int maa_ddim_update(maa_ctx* ctx, const float* d_x, const float* d_eps_uncond, c
                     const float* d_coef, int64_t n, float* d_x_prev, float* d_pred_x0);
 
 /* replaces: DDIMSampler.ddim_sampling (ddim.py:118-166), including mask / x0 blending, eta > 0 with the caller's noise and
- * the logged intermediates (score correctors, quantisation, dropout noise and host callbacks are not covered):
+ * the logged intermediates (score correctors, quantisation, dropout noise and host callbacks need host code between steps:
+ * the Python sampler runs such calls step by step over maa_unet_forward + maa_ddim_update):
  * runs S steps on the device without host round trips.
  *   d_x [B, C, H, W] in/out latent (x_T in, x_0 out)
  *   d_cond / d_uncond [B, L, context_dim] (crossattn; d_uncond NULL or scale == 1 -> no CFG), or for the
@@ -220,6 +221,9 @@ typedef struct maa_vocoder_config {
     /* NSF branch (h['use_pitch_embed'], NeuralSeq/modules/hifigan/hifigan.py:111-115,124-132): harmonic-plus-noise source
      * of `harmonic_num` overtones at `sampling_rate` (h['audio_sample_rate']), added through noise_convs after each ups[i] */
     int use_pitch_embed, sampling_rate, harmonic_num;
+    /* h.resblock: 1 (or 0) = ResBlock1 / AMPBlock1 (`convs1` + `convs2`), 2 = ResBlock2 / AMPBlock2 (`convs`: one dilated
+     * convolution per residual step; hifigan.py:70-91,119, vocoder/hifigan/modules.py:62-83,93, bigvgan/models.py:90-132,146) */
+    int resblock;
 } maa_vocoder_config;
 /* tensors: generator state_dict (weight_g/weight_v pairs or folded `weight`), keys as
  * NeuralSeq/modules/hifigan/hifigan.py:104-142 / vocoder/bigvgan/models.py:133-179 */

@@ -64,7 +64,7 @@ def q_sample_tables(ac, steps):
 
 def ddim_sample(apply_model, ac, S, x_T, cond, uncond=None, scale=1.0, eta=0.0, noise_fn=None,
                 trace=None, mask=None, x0=None, noise_q=None, noise_p=None, temperature=1.0, log_every_t=None,
-                q_tables=None):
+                q_tables=None, score_fn=None, callback=None, img_callback=None):
     """ddim.py:118-166 + 169-225.
 
     apply_model(x, t, c) -> eps;  `cond`/`uncond` are tensors (crossattn context or concat cond).
@@ -72,6 +72,9 @@ def ddim_sample(apply_model, ac, S, x_T, cond, uncond=None, scale=1.0, eta=0.0, 
     mask / x0 / noise_q [S, ...]: img = q_sample(x0, t) * mask + (1 - mask) * img before every step (ddim.py:147-150), with the
     step's draw of randn_like(x0) given in loop order; noise_p [S, ...]: the steps' noise_like draws (ddim.py:221), scaled by
     sigma_t and `temperature`; log_every_t: also return the intermediates dict of ddim.py:138, 161-163.
+    Host code inside the loop: score_fn(e_t, x, ts, cond) -> e_t stands for `score_corrector.modify_score(model, e_t, x, t, c,
+    **corrector_kwargs)` (ddim.py:201-203, after the guidance mix); callback(i) and img_callback(pred_x0, i) run after every step
+    (ddim.py:155-156), i counting from 0.
     """
     steps = ddim_timesteps(S, ac.shape[0])
     alphas, alphas_prev, sigmas, somas = ddim_tables(ac, steps, eta)
@@ -95,6 +98,8 @@ def ddim_sample(apply_model, ac, S, x_T, cond, uncond=None, scale=1.0, eta=0.0, 
             c_in = torch.cat([uncond, cond])
             e_u, e_c = apply_model(x_in, t_in, c_in).chunk(2)
             e_t = e_u + scale * (e_c - e_u)
+        if score_fn is not None:
+            e_t = score_fn(e_t, x, ts, cond)
         if noise_p is not None:
             noise = noise_p[i] if eta > 0 else None
         else:
@@ -110,6 +115,10 @@ def ddim_sample(apply_model, ac, S, x_T, cond, uncond=None, scale=1.0, eta=0.0, 
             x, x0_pred = ddim_step(x, e_t, alphas[index], alphas_prev[index], sigmas[index], somas[index], noise)
         if trace is not None:
             trace.append(x.clone())
+        if callback:
+            callback(i)
+        if img_callback:
+            img_callback(x0_pred, i)
         if log_every_t is not None and (index % log_every_t == 0 or index == total - 1):
             inter["x_inter"].append(x)
             inter["pred_x0"].append(x0_pred)

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .vocoder import LRELU_SLOPE, _resblock1
+from .vocoder import LRELU_SLOPE, resblock
 
 HARMONIC_NUM = 8            # hifigan.py:112
 SINE_AMP = 0.1              # source.py:493 default
@@ -71,7 +71,7 @@ def hifigan_nsf_forward(sd, cfg, mel, f0, rand_ini, noise):
         x = x + xs                                                           # :155-157
         acc = None
         for j, (rk, rd) in enumerate(zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"])):
-            r = _resblock1(sd, f"resblocks.{i * nk + j}.", x, rk, rd)
+            r = resblock(sd, cfg, f"resblocks.{i * nk + j}.", x, rk, rd)
             acc = r if acc is None else acc + r
         x = acc / nk
     x = F.leaky_relu(x)

@@ -1,9 +1,9 @@
 """Oracle: HiFi-GAN / BigVGAN MRF generators, functional CPU fp32.  TEST INFRASTRUCTURE ONLY.
 
 Restates:
-  /root/reference/NeuralSeq/modules/hifigan/hifigan.py:26-61, 104-178  (HifiGanGenerator, f0=None)
-  /root/reference/text_to_audio/Make_An_Audio/vocoder/hifigan/modules.py:22-59, 86-136 (Generator; same graph)
-  /root/reference/text_to_audio/Make_An_Audio/vocoder/bigvgan/models.py:30-81, 133-203 (AMPBlock1, BigVGAN)
+  /root/reference/NeuralSeq/modules/hifigan/hifigan.py:26-91, 104-178  (ResBlock1 / ResBlock2, HifiGanGenerator, f0=None)
+  /root/reference/text_to_audio/Make_An_Audio/vocoder/hifigan/modules.py:22-83, 86-136 (Generator; same graph)
+  /root/reference/text_to_audio/Make_An_Audio/vocoder/bigvgan/models.py:30-132, 133-203 (AMPBlock1 / AMPBlock2, BigVGAN)
   .../vocoder/bigvgan/activations.py:62-119 (Snake / SnakeBeta)
   .../vocoder/bigvgan/alias_free_torch/{act.py:8-27, filter.py:28-94, resample.py:10-49}
 State-dict keys follow the reference generators; weight-norm pairs (weight_g / weight_v) are folded
@@ -50,6 +50,20 @@ def _resblock1(sd, p, x, k, dil):
     return x
 
 
+def _resblock2(sd, p, x, k, dil):
+    """hifigan.py:83-88 (`resblock: "2"`): one dilated conv per residual step."""
+    for j, d in enumerate(dil):
+        xt = F.leaky_relu(x, LRELU_SLOPE)
+        xt = F.conv1d(xt, sd[p + f"convs.{j}.weight"], sd[p + f"convs.{j}.bias"], padding=_pad(k, d), dilation=d)
+        x = xt + x
+    return x
+
+
+def resblock(sd, cfg, p, x, k, dil):
+    """hifigan.py:119 / modules.py:93: `ResBlock1 if h.resblock == '1' else ResBlock2`."""
+    return (_resblock1 if str(cfg.get("resblock", "1")) == "1" else _resblock2)(sd, p, x, k, dil)
+
+
 def hifigan_forward(sd, cfg, mel):
     """hifigan.py:144-169 with f0=None.  mel [B,80,T] -> wav [B,1,T*hop].  `sd` has folded weights."""
     nk = len(cfg["resblock_kernel_sizes"])
@@ -59,7 +73,7 @@ def hifigan_forward(sd, cfg, mel):
         x = F.conv_transpose1d(x, sd[f"ups.{i}.weight"], sd[f"ups.{i}.bias"], stride=u, padding=(k - u) // 2)
         xs = None
         for j, (rk, rd) in enumerate(zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"])):
-            r = _resblock1(sd, f"resblocks.{i * nk + j}.", x, rk, rd)
+            r = resblock(sd, cfg, f"resblocks.{i * nk + j}.", x, rk, rd)
             xs = r if xs is None else xs + r
         x = xs / nk
     x = F.leaky_relu(x)          # slope 0.01 (hifigan.py:165)
@@ -139,6 +153,15 @@ def _ampblock1(sd, p, x, k, dil, cfg, filt):
     return x
 
 
+def _ampblock2(sd, p, x, k, dil, cfg, filt):
+    """bigvgan/models.py:122-128 (`resblock: "2"`)."""
+    for j, d in enumerate(dil):
+        xt = activation1d(sd, p + f"activations.{j}.", x, cfg, filt)
+        xt = F.conv1d(xt, sd[p + f"convs.{j}.weight"], sd[p + f"convs.{j}.bias"], padding=_pad(k, d), dilation=d)
+        x = xt + x
+    return x
+
+
 def bigvgan_forward(sd, cfg, mel):
     """bigvgan/models.py:181-203.  `sd` has folded weights; ups keys are `ups.{i}.0.*`."""
     nk = len(cfg["resblock_kernel_sizes"])
@@ -148,7 +171,8 @@ def bigvgan_forward(sd, cfg, mel):
         x = F.conv_transpose1d(x, sd[f"ups.{i}.0.weight"], sd[f"ups.{i}.0.bias"], stride=u, padding=(k - u) // 2)
         xs = None
         for j, (rk, rd) in enumerate(zip(cfg["resblock_kernel_sizes"], cfg["resblock_dilation_sizes"])):
-            r = _ampblock1(sd, f"resblocks.{i * nk + j}.", x, rk, rd, cfg, filt)
+            amp = _ampblock1 if str(cfg.get("resblock", "1")) == "1" else _ampblock2       # models.py:146
+            r = amp(sd, f"resblocks.{i * nk + j}.", x, rk, rd, cfg, filt)
             xs = r if xs is None else xs + r
         x = xs / nk
     x = activation1d(sd, "activation_post.", x, cfg, filt)

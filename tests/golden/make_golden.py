@@ -202,6 +202,58 @@ def ddim_full_signature_case(name, unet, S=6, scale=1.5, eta=0.5, temperature=0.
     print(name, "z std", float(z.std()), "logged", len(inter["x_inter"]))
 
 
+def ddim_host_hooks_case(name, unet, S=4, scale=1.5, eta=0.3, seed=41):
+    """The parts of DDIMSampler.sample that put HOST code inside the loop (ddim.py:154-156, 201-203): a score corrector
+    (`modify_score(model, e_t, x, t, c, **corrector_kwargs)`), `callback(i)` and `img_callback(pred_x0, i)`, on the T2A model with
+    guidance and eta > 0.  The corrector is an affine map of (e_t, x) so that the stored result pins the call order and the
+    arguments; the per-step noise draws are repeated afterwards from the same seed, as in ddim_full_signature_case."""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+    ldm = C.LDM_T2A
+
+    class Shim:
+        parameterization = "eps"            # asserted by p_sample_ddim when a corrector is given (ddim.py:202)
+
+        def __init__(self):
+            betas = make_beta_schedule("linear", ldm["timesteps"], ldm["linear_start"], ldm["linear_end"])
+            ac = np.cumprod(1.0 - betas, axis=0)
+            self.num_timesteps = ldm["timesteps"]
+            self.betas = torch.tensor(betas, dtype=torch.float32)
+            self.alphas_cumprod = torch.tensor(ac, dtype=torch.float32)
+            self.alphas_cumprod_prev = torch.tensor(np.append(1.0, ac[:-1]), dtype=torch.float32)
+            self.device = torch.device("cpu")
+
+        def apply_model(self, x, t, c):
+            return unet(x, t, context=c)
+
+    class Corrector:
+        def modify_score(self, model, e_t, x, t, c, gain, shift):
+            assert isinstance(model, Shim) and t.dtype == torch.long and c.shape[0] == x.shape[0]
+            return gain * e_t + shift * x * (t.float() / 1000.0).reshape(-1, 1, 1, 1)
+
+    shim = Shim()
+    sampler = DDIMSampler(shim)
+    sampler.device = torch.device("cpu")
+    n = 2
+    x_T = torch.from_numpy(np.random.RandomState(57).randn(n, 4, 10, 78)).float()
+    c, uc = _cond(n, 77, 1234), _cond(n, 77, 1235)
+    seen, preds = [], []
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        z, inter = sampler.sample(S=S, conditioning=c, batch_size=n, shape=[4, 10, 78], verbose=False, eta=eta,
+                                  unconditional_guidance_scale=scale, unconditional_conditioning=uc, x_T=x_T, log_every_t=3,
+                                  score_corrector=Corrector(), corrector_kwargs=dict(gain=0.9, shift=0.05),
+                                  callback=seen.append, img_callback=lambda p, i: preds.append((i, p.clone())))
+    torch.manual_seed(seed)
+    npp = [torch.randn(x_T.shape) for _ in range(len(sampler.ddim_timesteps))]
+    assert seen == list(range(len(sampler.ddim_timesteps))) and [i for i, _ in preds] == seen
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), x_T=x_T.numpy(), c=c.numpy(), uc=uc.numpy(),
+                        noise_p=torch.stack(npp).numpy(), z=z.numpy(), pred_x0_steps=np.stack([p.numpy() for _, p in preds]),
+                        x_inter=np.stack([t.numpy() for t in inter["x_inter"]]), callback_i=np.asarray(seen),
+                        S=S, scale=scale, eta=eta, gain=0.9, shift=0.05, log_every_t=3, seed=seed)
+    print(name, "z std", float(z.std()), "steps", len(seen), "logged", len(inter["x_inter"]))
+
+
 def ddim_variant_case(name, unet, ldm, S, scale, ctx_len=None):
     """The reference DDIMSampler on the other two tools' call patterns:
     inpaint -- conditioning_key 'concat' (ddpm.py:1404-1406: unet(cat([x] + [c], 1), t)), no guidance (audio-chatgpt.py:513-518);
@@ -941,6 +993,7 @@ def main():
     ddim_variant_case("ddim_i2a_s4", u_i2a, C.LDM_I2A, 4, 3.0, ctx_len=1)
     ddim_variant_case("ddim_inpaint_s4", u_inp, C.LDM_INPAINT, 4, 1.0)
     ddim_full_signature_case("ddim_t2a_mask_eta_s6", unet)
+    ddim_host_hooks_case("ddim_t2a_host_hooks_s4", unet)
     mel = vae_case("vae", C.VAE_DDCONFIG, manifest, z=z)
     # plumbing config 1 end to end: clamp((x+1)/2, 0, 1) -> vocoder (audio-chatgpt.py:176-181)
     spec = torch.clamp((mel + 1.0) / 2.0, 0.0, 1.0)[:, 0]
@@ -948,6 +1001,8 @@ def main():
     hifigan_case("hifigan_ns512", C.HIFIGAN_NS_512, 64, manifest, B=2)
     hifigan_case("hifigan_ns128", C.HIFIGAN_NS_128, 96, manifest, B=2)
     bigvgan_case("bigvgan_16k", C.BIGVGAN_16K, 48, manifest)
+    hifigan_case("hifigan_rb2", C.HIFIGAN_RB2, 72, manifest, B=2, seed=12)
+    bigvgan_case("bigvgan_rb2", C.BIGVGAN_RB2, 40, manifest, seed=13)
     hifigan_nsf_case("hifigan_nsf_24k", C.HIFIGAN_NSF_24K, 40, manifest)
     diffsinger_case("diffsinger_ds1000", C.DIFFSINGER_DS1000, 48, manifest)
     config2_case("t2a_config2_s100")
@@ -988,11 +1043,33 @@ def main_nsf_only():
     print("torch", torch.__version__)
 
 
+def main_resblock2_only():
+    """`python tests/golden/make_golden.py resblock2`: the generators' other residual block (`resblock: "2"`) through the
+    reference's own Generator / HifiGanGenerator (ResBlock2) and BigVGAN (AMPBlock2, plain `snake`)."""
+    torch.set_num_threads(8)
+    _install_shims()
+    with open(os.path.join(HERE, "manifest.json")) as f:
+        manifest = json.load(f)
+    hifigan_case("hifigan_rb2", C.HIFIGAN_RB2, 72, manifest, B=2, seed=12)
+    bigvgan_case("bigvgan_rb2", C.BIGVGAN_RB2, 40, manifest, seed=13)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    print("torch", torch.__version__)
+
+
 def main_ddim_full_only():
     """`python tests/golden/make_golden.py ddimfull`: the mask / eta / intermediates case of the sampler only."""
     _install_shims()
     u = unet_case("unet_t2a", C.UNET_T2A, 10, 78, 77, {}, save=False)
     ddim_full_signature_case("ddim_t2a_mask_eta_s6", u)
+
+
+def main_ddim_hooks_only():
+    """`python tests/golden/make_golden.py ddimhooks`: the score-corrector / callback case of the sampler only."""
+    torch.set_num_threads(8)
+    _install_shims()
+    u = unet_case("unet_t2a", C.UNET_T2A, 10, 78, 77, {}, save=False)
+    ddim_host_hooks_case("ddim_t2a_host_hooks_s4", u)
 
 
 def main_ddim_variants_only():
@@ -1009,4 +1086,5 @@ def main_ddim_variants_only():
 
 if __name__ == "__main__":
     {"nsf": main_nsf_only, "ddimvar": main_ddim_variants_only, "ddimfull": main_ddim_full_only, "diffsinger": main_diffsinger_only,
-     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only, "cliptext": main_clip_text_only, "clapaudio": main_clap_audio_only, "clapscore": main_clap_score_only, "mixed": main_mixed_only}.get(" ".join(sys.argv[1:]), main)()
+     "config2": main_config2_only, "config3": main_config3_only, "encoders": main_encoders_only, "cliptext": main_clip_text_only, "clapaudio": main_clap_audio_only, "clapscore": main_clap_score_only, "mixed": main_mixed_only,
+     "resblock2": main_resblock2_only, "ddimhooks": main_ddim_hooks_only}.get(" ".join(sys.argv[1:]), main)()

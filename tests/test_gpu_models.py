@@ -152,6 +152,22 @@ def test_bigvgan_matches_reference(golden, ctx):
     v.close()
 
 
+@pytest.mark.parametrize("name,cfg,seed,tol", [("hifigan_rb2", C.HIFIGAN_RB2, 12, 2e-4), ("bigvgan_rb2", C.BIGVGAN_RB2, 13, 5e-4)])
+def test_resblock2_generators_match_reference(golden, ctx, name, cfg, seed, tol):
+    """`resblock: "2"` (VERDICT r5 missing #5): ResBlock2 (hifigan.py:70-91, modules.py:62-83) and AMPBlock2 with plain
+    `snake` (bigvgan/models.py:90-132) against the reference generators' own outputs."""
+    from audiogpt_amd.backend import Vocoder
+    g = golden(name)
+    v = Vocoder(ctx, cfg, WT.make_vocoder_state_dict(cfg, seed=seed))
+    wav = v(torch.from_numpy(g["mel"])).cpu()
+    ref = torch.from_numpy(g["wav"])
+    rms = float(((wav - ref) ** 2).mean().sqrt())
+    record(name + "_wav_rms", wav_rms=rms, tol=1e-4)
+    check(name + "_vs_reference", wav, ref, tol)
+    assert rms <= 1e-4
+    v.close()
+
+
 def test_t2a_plumbing_config1_end_to_end(golden, ctx, unet_t2a, vae):
     """BASELINE config 1: 1 prompt, 10 DDIM steps, CFG 1.5 -> VAE -> clamp -> HiFi-GAN, vs the reference chain."""
     from audiogpt_amd.backend import Vocoder

@@ -261,7 +261,8 @@ def test_bf16x3_vae_decode_and_encode_match_reference(golden, ctx3):
 
 
 @pytest.mark.parametrize("name,cfg,seed,tol", [("hifigan_16k_t2a", C.HIFIGAN_16K, 2, 2e-4), ("hifigan_ns512", C.HIFIGAN_NS_512, 2, 2e-4),
-                                               ("hifigan_ns128", C.HIFIGAN_NS_128, 2, 2e-4), ("bigvgan_16k", C.BIGVGAN_16K, 3, 5e-4)])
+                                               ("hifigan_ns128", C.HIFIGAN_NS_128, 2, 2e-4), ("bigvgan_16k", C.BIGVGAN_16K, 3, 5e-4),
+                                               ("hifigan_rb2", C.HIFIGAN_RB2, 12, 2e-4), ("bigvgan_rb2", C.BIGVGAN_RB2, 13, 5e-4)])
 def test_bf16x3_vocoders_match_reference(golden, ctx3, name, cfg, seed, tol):
     from audiogpt_amd.backend import Vocoder
     gg = golden(name)

@@ -134,11 +134,59 @@ def test_ddim_sampler_mask_eta_intermediates_match_reference(golden, precision):
     torch.manual_seed(123)
     sampler.sample(**kw)
     assert torch.equal(torch.randn(3, device="cuda"), after)
-    # what still has no device form says so
-    with pytest.raises(NotImplementedError):
-        sampler.sample(noise_dropout=0.1, **kw)
     with pytest.raises(AssertionError):
         sampler.sample(**dict(kw, x0=None))
+    # host code inside the loop takes the per-step loop (next test); with hooks that change nothing it lands on the device
+    # loop's result (same kernels for the UNet passes; the update kernel of the per-step form has the same arithmetic)
+    seen = []
+    zh, ih = sampler.sample(_step_noise=(t("noise_q"), t("noise_p")), callback=seen.append, **kw)
+    assert seen == list(range(7)) and len(ih["x_inter"]) == len(inter["x_inter"])
+    check(f"tools_{precision}_DDIMSampler.host_loop_vs_device_loop", zh, z, 1e-5)
+    # noise_dropout (ddim.py:222-223): F.dropout of the step's noise term -- every element of the last step's noise is either
+    # dropped or scaled by 1 / (1 - p); checked on a one-step trajectory against the same call without dropout
+    one = dict(kw, S=1, mask=None, x0=None, log_every_t=1)
+    nz = t("noise_p")[:1]
+    za, _ = sampler.sample(_step_noise=(None, nz), callback=lambda i: None, **one)
+    zb, _ = sampler.sample(_step_noise=(None, nz), noise_dropout=0.5, **one)
+    sig = float(np.asarray(sampler.ddim_sigmas, dtype=np.float32)[0]) * float(g["temperature"])
+    n1 = sig * nz[0]                                       # (kept: x + 2 n) - (x + n) = +n ; dropped: x - (x + n) = -n
+    assert sig > 0 and float(((zb - za).abs() - n1.abs()).abs().max()) < 1e-5
+    big = n1.abs() > 0.1 * sig
+    assert 0.4 < float((((zb - za) * n1)[big] > 0).float().mean()) < 0.6
+    with pytest.raises(AttributeError):          # the KL first stage has no `quantize`, as in the reference (ddim.py:213-214)
+        sampler.sample(_step_noise=(None, nz), quantize_x0=True, **one)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_ddim_sampler_host_hooks_match_reference(golden, precision):
+    """VERDICT r5 missing #4: score_corrector / corrector_kwargs / callback / img_callback (ddim.py:59-115, 154-156, 201-203)
+    against the reference sampler's own run with an affine corrector (make_golden.py ddim_host_hooks_case)."""
+    from audiogpt_amd.ldm.ddim import DDIMSampler
+    g = golden("ddim_t2a_host_hooks_s4")
+    model = _cached("ldm_t2a", precision)
+    sampler = DDIMSampler(model)
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    gain, shift = float(g["gain"]), float(g["shift"])
+
+    class Corrector:
+        def modify_score(self, m, e_t, x, ts, c, gain, shift):
+            assert m is model and ts.dtype == torch.long and c.shape[0] == x.shape[0]
+            return gain * e_t + shift * x * (ts.float() / 1000.0).reshape(-1, 1, 1, 1)
+
+    seen, preds = [], []
+    z, inter = sampler.sample(S=int(g["S"]), conditioning=t("c"), batch_size=2, shape=[4, 10, 78], verbose=False, eta=float(g["eta"]),
+                              unconditional_guidance_scale=float(g["scale"]), unconditional_conditioning=t("uc"), x_T=t("x_T"),
+                              log_every_t=int(g["log_every_t"]), score_corrector=Corrector(),
+                              corrector_kwargs=dict(gain=gain, shift=shift), callback=seen.append,
+                              img_callback=lambda p, i: preds.append((i, p.clone())), _step_noise=(None, t("noise_p")))
+    assert seen == g["callback_i"].tolist() == [i for i, _ in preds]
+    tol = 2e-3 if precision == "bf16x3" else 1e-3
+    for i, p in preds:
+        check(f"tools_{precision}_DDIMSampler.host_hooks_pred_x0_{i}", p, g["pred_x0_steps"][i], tol)
+    assert len(inter["x_inter"]) == g["x_inter"].shape[0]
+    for i in range(len(inter["x_inter"])):
+        check(f"tools_{precision}_DDIMSampler.host_hooks_x_inter{i}", inter["x_inter"][i], g["x_inter"][i], tol)
+    check(f"tools_{precision}_DDIMSampler.host_hooks_z", z, g["z"], tol)
 
 
 # ------------------------------------------------------------------------------------------------ T2A
