@@ -124,7 +124,8 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
             MAA_HIP(hipEventRecord(ctx.ev_join, lane2->stream));
             MAA_HIP(hipStreamWaitEvent(ctx.stream, ctx.ev_join, 0));
         } else
-            unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps, emb_hoist ? cur_emb : nullptr);
+            // (one stream: the halves of cat([x] * 2) share every layer before the first cross-attention -- unet.cpp `dup`)
+            unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps, emb_hoist ? cur_emb : nullptr, -1, cfg && emb_hoist);
         launch_ddim_step(ctx, xin, per, per_in, eps, cfg ? eps + a.B * per : nullptr, a.scale, cur_coef, (long long)a.B * per, xs,
                          a.h_sigmas ? a.d_noise_p : nullptr, a.temperature, a.S, logging ? a.d_log_x : nullptr,
                          logging ? a.d_log_x0 : nullptr, d_step);

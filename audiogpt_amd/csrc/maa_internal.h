@@ -135,6 +135,7 @@ struct Tuning {
     bool op_presplit = false;               // MAA_OP_PRESPLIT=1: the maa_op_* test entry points hand activations over as split32
     bool no_dma = false;                    // MAA_NO_DMA: every bf16 contraction on the register-staged engine (bit-identity tests)
     int halo = 2;                           // MAA_HALO = "off": the narrow vocoder stages through the implicit GEMM; "single": their MRF pairs as two halo launches; default: fused pairs (bit-identity tests)
+    bool cfg_shared = true;                 // MAA_CFG_SHARED=0: a guided DDIM step on one stream evaluates both halves of cat([x] * 2) in full (rounds 1-6a) instead of computing the layers before the first cross-attention once
     bool gn_two_pass = false;               // MAA_GN_TWO_PASS=1: GroupNorm as the statistics + apply launches everywhere (the VAE's large images always take them; tests)
     void load();
 };
@@ -301,6 +302,8 @@ void launch_nchw_to_nhwc(const Ctx& ctx, const float* x, int B, int C, int HW, f
 void launch_nhwc_to_nchw(const Ctx& ctx, const float* x, int B, int C, int HW, float* out, int ld_in);
 void launch_avgpool2(const Ctx& ctx, const float* x, int B, int H, int W, int C, float* out);
 void launch_upsample2(const Ctx& ctx, const float* x, int B, int H, int W, int C, float* out);
+// out[0 .. n) = out[n .. 2n) = x[0 .. n)   (n % 4 == 0): the two halves of a guided step's batch leave their shared prefix
+void launch_dup_half(const Ctx& ctx, const float* x, long long n, float* out);
 void launch_scale(const Ctx& ctx, const float* x, long long n, float s, float* out);
 // eps = eu + scale*(ec - eu); x0 = (x - somat*eps)/sqrt(a_t); x' = sqrt(a_prev)*x0 + sqrt(1-a_prev-sig^2)*eps
 // coef = device pointer to {a_t, a_prev, sigma, sqrt_one_minus_at}; eps_c may be null (no CFG)

@@ -457,6 +457,16 @@ __global__ __launch_bounds__(256) void snake_aa_tiled_kernel(const float* __rest
     }
 }
 
+// the two halves of a guided DDIM step's batch, cat([x] * 2), are one tensor until the first cross-attention (unet.cpp): the
+// layers before it run on one half and this copy makes the [2B] tensor the rest of the network reads
+__global__ void dup_half_kernel(const float4* __restrict__ x, long long n4, float4* __restrict__ out) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = x[i];
+        out[i] = v;
+        out[i + n4] = v;
+    }
+}
+
 }  // namespace
 
 #define MAA_LAUNCH1(kern, n, ...)                                                            \
@@ -508,6 +518,10 @@ void launch_pixel_shuffle2(const Ctx& ctx, const float* planes, int B, int H, in
     MAA_CHECK(C % 4 == 0, "pixel_shuffle2: channels must be a multiple of 4");
     MAA_LAUNCH1(pixel_shuffle2_kernel, (long long)B * H * W * C, reinterpret_cast<const float4*>(planes), B, H, W, C / 4,
                 reinterpret_cast<float4*>(out));
+}
+void launch_dup_half(const Ctx& ctx, const float* x, long long n, float* out) {
+    MAA_CHECK(n % 4 == 0, "dup_half: element count must be a multiple of 4");
+    MAA_LAUNCH1(dup_half_kernel, n / 4, reinterpret_cast<const float4*>(x), n / 4, reinterpret_cast<float4*>(out));
 }
 void launch_avgpool2(const Ctx& ctx, const float* x, int B, int H, int W, int C, float* out) {
     MAA_LAUNCH1(avgpool2_kernel, (long long)B * (H / 2) * (W / 2) * C, x, B, H, W, C, out);

@@ -169,6 +169,7 @@ void Tuning::load() {
     if (pp_s_wide < 1) pp_s_wide = 1;
     pp_tile_major = get_s("MAA_PP_TILE_MAJOR") == "1";
     up2 = get_s("MAA_UP2") != "0";
+    cfg_shared = get_s("MAA_CFG_SHARED") != "0";
     const std::string ps = get_s("MAA_OP_PRESPLIT");
     op_presplit = !ps.empty() && ps[0] == '1';
     no_dma = !get_s("MAA_NO_DMA").empty();

@@ -11,6 +11,10 @@
 //   * to_q/to_k/to_v of self-attention are one GEMM (N = 3*inner); the cross-attention K/V projections of the
 //     (step-invariant) context are computed once per `set_context` and reused by every DDIM step
 //   * bias, time-embedding add, residual add and GEGLU are igemm epilogues
+//   * a guided DDIM step evaluates the model on cat([x] * 2) with cat([uncond, cond]) (ddim.py:177-199): the two halves differ
+//     only in the context, so every layer before the first cross-attention (conv_in, the first ResBlock, the first
+//     transformer's norm / proj_in / self-attention / to_q) is the same tensor twice -- computed on one half and duplicated
+//     where the halves part (forward_body `dup`; round 6).  Every kernel is batch-invariant, so the result is bit-identical.
 #include "models.h"
 
 #include <atomic>
@@ -319,11 +323,22 @@ struct UNet::Impl {
         return out;
     }
 
-    T4 run_st(Ctx& ctx, const STW& s, const T4& x) {
-        const int B = x.B, HW = x.H * x.W, inner = s.heads * s.dh;
-        const long long M = (long long)B * HW;
-        T4 out = alloc_t(ctx, B, x.H, x.W, s.ch);
+    // expand: x holds ONE half of a guided step's batch (both halves are equal up to here); the block's first cross-attention
+    // is where they part, so everything before it runs on x.B samples and the output has 2 x.B
+    T4 run_st(Ctx& ctx, const STW& s, const T4& x, bool expand = false) {
+        const int HW = x.H * x.W, inner = s.heads * s.dh;
+        int B = x.B;                                   // samples of the current tensors
+        const int Bo = expand ? 2 * x.B : x.B;
+        long long M = (long long)B * HW;
+        const long long Mo = (long long)Bo * HW;
+        T4 out = alloc_t(ctx, Bo, x.H, x.W, s.ch);
         const size_t mk = ctx.ws.mark();
+        const float* xres = x.p;                       // proj_out's residual: the block input, for every output sample
+        if (expand) {
+            float* xd = ctx.ws.alloc_f((size_t)Mo * s.ch);
+            launch_dup_half(ctx, x.p, M * s.ch, xd);
+            xres = xd;
+        }
         float* xn = ctx.ws.alloc_f((size_t)M * s.ch);
         const bool sp_in = split_for_gemm(ctx, s.ch), sp = split_for_gemm(ctx, inner);
         launch_groupnorm(ctx, x.p, s.ch, s.ch, nullptr, 0, 0, B, HW, 32, s.ng, s.nb, 1e-6f, 0, xn, sp_in);
@@ -337,8 +352,8 @@ struct UNet::Impl {
         const int g_sp = !no_osplit && split_for_gemm(ctx, 4 * inner) ? 1 : 0;
         int y_sp = 0;
         for (const STBlockW& b : s.blocks) {
-            float* ln = ctx.ws.alloc_f((size_t)M * inner);
-            float* o = ctx.ws.alloc_f((size_t)M * inner);
+            float* ln = ctx.ws.alloc_f((size_t)Mo * inner);
+            float* o = ctx.ws.alloc_f((size_t)Mo * inner);
             // x = attn1(norm1(x)) + x      (attention.py:212)
             launch_layernorm(ctx, y, M, inner, b.ln1g, b.ln1b, 1e-5f, ln, sp);
             float* qkv = ctx.ws.alloc_f((size_t)M * 3 * inner);
@@ -351,6 +366,16 @@ struct UNet::Impl {
             launch_layernorm(ctx, y1, M, inner, b.ln2g, b.ln2b, 1e-5f, ln, sp);
             float* q = ctx.ws.alloc_f((size_t)M * inner);
             linear_into(ctx, ln, inner, M, inner, b.q2, nullptr, 0, q, inner, 0, 0, sp ? M : 0);
+            if (B != Bo) {      // the halves part here: the same queries and the same residual stream meet two contexts
+                float* qd = ctx.ws.alloc_f((size_t)Mo * inner);
+                float* yd = ctx.ws.alloc_f((size_t)Mo * inner);
+                launch_dup_half(ctx, q, M * inner, qd);
+                launch_dup_half(ctx, y1, M * inner, yd);
+                q = qd;
+                y1 = yd;
+                B = Bo;
+                M = Mo;
+            }
             MAA_CHECK(ctx.ws.dry || (kv_cache[b.kv_slot] && (lane ? batch_off + B <= kv_batch : kv_batch == B)),
                       "set_context must precede forward (batch)");
             const float* kv = kv_cache[b.kv_slot] + (size_t)batch_off * kv_len * 2 * inner;
@@ -370,7 +395,8 @@ struct UNet::Impl {
             linear_into(ctx, g, 4 * inner, M, 4 * inner, b.ff2, y2, inner, y3, inner, 0, 0, g_sp ? M : 0, y_sp);
             y = y3;
         }
-        linear_into(ctx, y, inner, M, inner, s.proj_out, x.p, s.ch, out.p, s.ch, 0, 0, y_sp ? M : 0);
+        MAA_CHECK(B == Bo, "SpatialTransformer without a transformer block cannot part the halves of a guided step");
+        linear_into(ctx, y, inner, M, inner, s.proj_out, xres, s.ch, out.p, s.ch, 0, 0, y_sp ? M : 0);
         ctx.ws.release(mk);
         return out;
     }
@@ -396,7 +422,8 @@ struct UNet::Impl {
         return out;
     }
 
-    T4 run_layers(Ctx& ctx, const std::vector<Layer>& layers, T4 h, const T4* skip, const float* emb_out) {
+    // shared (in/out): h holds one half of a guided step's batch; cleared by the SpatialTransformer that parts the halves
+    T4 run_layers(Ctx& ctx, const std::vector<Layer>& layers, T4 h, const T4* skip, const float* emb_out, bool* shared = nullptr) {
         bool first = true;
         for (const Layer& l : layers) {
             const T4* x2 = first ? skip : nullptr;
@@ -414,7 +441,8 @@ struct UNet::Impl {
                     h = run_res(ctx, res[l.idx], h, x2, emb_out);
                     break;
                 case kST:
-                    h = run_st(ctx, st[l.idx], h);
+                    h = run_st(ctx, st[l.idx], h, shared && *shared);
+                    if (shared) *shared = false;
                     break;
                 case kAttn:
                     h = run_attn(ctx, attn[l.idx], h);
@@ -470,12 +498,14 @@ struct UNet::Impl {
     bool lane = false;
 
     // emb_row != null: the step's ResBlock time-embedding row computed beforehand (UNet::emb_table), shared by all samples
+    // dup: the batch is cat([x] * 2) of a guided step with one time-embedding row for all samples (emb_row)
     void forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
-                 float* out_nchw, const float* emb_row = nullptr) {
+                 float* out_nchw, const float* emb_row = nullptr, bool dup = false) {
         if (context && batch_off) context += (size_t)batch_off * kv_len * cfg.context_dim;
         if (emb_row) {
             emb_ld = 0;
-            forward_body(ctx, x_nchw, B, H, W, out_nchw, emb_row);
+            forward_body(ctx, x_nchw, B, H, W, out_nchw, emb_row,
+                         dup && ctx.tune.cfg_shared && cfg.use_spatial_transformer && !lane && B % 2 == 0);
             return;
         }
         float* emb_out = ctx.ws.alloc_f((size_t)B * emb_all.Npad);
@@ -484,14 +514,27 @@ struct UNet::Impl {
         forward_body(ctx, x_nchw, B, H, W, out_nchw, emb_out);
     }
 
-    void forward_body(Ctx& ctx, const float* x_nchw, int B, int H, int W, float* out_nchw, const float* emb_out) {
+    void forward_body(Ctx& ctx, const float* x_nchw, int B, int H, int W, float* out_nchw, const float* emb_out,
+                      bool dup = false) {
         const int mc = cfg.model_channels;
-        T4 h = alloc_t(ctx, B, H, W, cfg.in_channels);
-        launch_nchw_to_nhwc(ctx, x_nchw, B, cfg.in_channels, H * W, h.p);
+        // dup: samples [B/2, B) repeat samples [0, B/2) (x and the embedding row); only the context rows differ, and the context
+        // enters at the first cross-attention -- until then one half is computed and the skip tensors are written twice
+        bool shared = dup;
+        auto both = [&](const T4& t) {
+            T4 d = alloc_t(ctx, 2 * t.B, t.H, t.W, t.C);
+            launch_dup_half(ctx, t.p, (long long)t.B * t.H * t.W * t.C, d.p);
+            return d;
+        };
+        T4 h = alloc_t(ctx, shared ? B / 2 : B, H, W, cfg.in_channels);
+        launch_nchw_to_nhwc(ctx, x_nchw, h.B, cfg.in_channels, H * W, h.p);
         std::vector<T4> hs;
         for (auto& blk : input) {
-            h = run_layers(ctx, blk, h, nullptr, emb_out);
-            hs.push_back(h);
+            h = run_layers(ctx, blk, h, nullptr, emb_out, &shared);
+            hs.push_back(shared ? both(h) : h);
+        }
+        if (shared) {          // (no transformer on the way down: the halves part at the middle block at the latest)
+            h = both(h);
+            shared = false;
         }
         h = run_layers(ctx, middle, h, nullptr, emb_out);
         for (auto& blk : output) {
@@ -567,13 +610,13 @@ void UNet::set_context_cfg(Ctx& ctx, const float* d_uncond, const float* d_cond,
 }
 
 void UNet::forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
-                   float* out_nchw, const float* emb_row, int batch_off) {
+                   float* out_nchw, const float* emb_row, int batch_off, bool cfg_dup) {
     Impl& m = *impl_;
     PrecisionGuard pg(ctx, m.precision);
     m.lane = batch_off >= 0;
     m.batch_off = m.lane ? batch_off : 0;
     try {
-        run_sized(ctx, [&] { m.forward(ctx, x_nchw, t, context, B, H, W, out_nchw, emb_row); });
+        run_sized(ctx, [&] { m.forward(ctx, x_nchw, t, context, B, H, W, out_nchw, emb_row, cfg_dup); });
     } catch (...) {
         m.batch_off = 0;
         m.lane = false;

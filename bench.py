@@ -94,7 +94,7 @@ def main(argv=None):
     ap.add_argument("--cfg-split", default="auto", choices=["auto", "0", "1"],
                     help="classifier-free guidance inside the sampler: 1 = the two halves of a step as two lanes (branches of the "
                          "captured step graph), 0 = one stream, auto = lanes only when ONE batch is in flight (--inflight 1): with "
-                         "several replicas the chip is already full from outside and six concurrent lanes lose 24 %")
+                         "several replicas the chip is already full from outside and six concurrent lanes lose 24 %%")
     ap.add_argument("--force-collectives", action="store_true",
                     help="initialise the process group and issue C1 scatter / broadcast, C2 gather, the barriers and ranks_seen even "
                          "with ONE rank (RCCL exercised on the one GPU a test box has: tests/test_gpu_rccl.py)")

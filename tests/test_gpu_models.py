@@ -270,6 +270,57 @@ def test_cfg_halves_as_two_lanes_are_bit_identical_to_one_stream(golden, precisi
 
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_guided_step_shares_the_layers_before_the_first_cross_attention(golden, precision):
+    """Round 6: a guided step evaluates the model on cat([x] * 2) (ddim.py:177-199); the halves differ only in the context, so
+    conv_in, the first ResBlock and the first transformer's norm / proj_in / self-attention / to_q are computed ONCE on the
+    one-stream form (unet.cpp `dup`) and duplicated where the halves part.  MAA_CFG_SHARED=0 evaluates both halves in full (what
+    rounds 1-5 did): the latent must be the same bit for bit -- plain, with mask + eta > 0 + intermediates, graph and eager, a
+    batch of one -- and the profiler must see fewer attention / convolution FLOPs with the shared prefix."""
+    import os
+    from audiogpt_amd.backend import Context, UNet, reload_tuning
+    g, gm = golden("ddim_t2a_s10"), golden("ddim_t2a_mask_eta_s6")
+    c = Context("cuda:0", precision=precision)
+    c.set_cfg_split(False)
+    u = UNet(c, C.UNET_T2A, WT.make_unet_state_dict(C.UNET_T2A, seed=0))
+    steps, a, ap = _ddim_tables(4, C.LDM_T2A)
+    t = lambda k: torch.from_numpy(gm[k])
+    from oracle import ddim as O
+    ac = O.alphas_cumprod(C.LDM_T2A["timesteps"], C.LDM_T2A["linear_start"], C.LDM_T2A["linear_end"])
+    sig = O.ddim_tables(ac, steps, 0.5)[2].numpy()
+    sq_ac, sq_1mac = (v.numpy() for v in O.q_sample_tables(ac, steps))
+    full = dict(cond=t("c"), uncond=t("uc"), scale=1.5, mask=t("mask"), x0=t("x0"), noise_q=t("noise_q")[:len(steps)],
+                sqrt_ac=sq_ac, sqrt_1mac=sq_1mac, sigmas=sig, noise_p=t("noise_p")[:len(steps)], temperature=0.9, log_every_t=1)
+    plain = dict(cond=torch.from_numpy(g["c"]), uncond=torch.from_numpy(g["uc"]), scale=float(g["scale"]))
+    out, flops = {}, {}
+    try:
+        for shared in ("1", "0"):
+            os.environ["MAA_CFG_SHARED"] = shared
+            reload_tuning()
+            x = torch.from_numpy(g["x_T"])
+            out[shared, "eager"] = u.ddim_sample(x, steps, a, ap, use_graph=False, **plain).cpu()
+            out[shared, "graph"] = u.ddim_sample(x, steps, a, ap, use_graph=True, **plain).cpu()
+            out[shared, "one"] = u.ddim_sample(x[:1], steps, a, ap, use_graph=True, cond=plain["cond"][:1], uncond=plain["uncond"][:1],
+                                               scale=plain["scale"]).cpu()
+            z, xi, p0 = u.ddim_sample(t("x_T"), steps, a, ap, use_graph=True, **full)
+            out[shared, "full"] = torch.cat([z.cpu().flatten(), xi.cpu().flatten(), p0.cpu().flatten()])
+            c.prof_begin()
+            u.ddim_sample(x, steps[:1], a[:1], ap[:1], use_graph=False, **plain)
+            rows = c.prof_end()
+            flops[shared] = sum(v["flops"] for v in rows.values())
+    finally:
+        os.environ.pop("MAA_CFG_SHARED", None)
+        reload_tuning()
+    assert float(out["0", "eager"].abs().max()) > 0
+    for k in ("eager", "graph", "one", "full"):
+        assert bool(torch.isfinite(out["0", k]).all()) and torch.equal(out["1", k], out["0", k]), k
+    assert torch.equal(out["1", "eager"], out["1", "graph"]) and torch.equal(out["1", "one"], out["1", "graph"][:1])
+    # conv_in + two 320 -> 320 convolutions + four 320-wide linears + one 780-token self-attention on half the batch
+    assert 0.93 * flops["0"] < flops["1"] < 0.985 * flops["0"], flops
+    u.close()
+    c.close()
+
+
 def test_serving_arrangement_hint_changes_tiles_and_lanes_but_not_results(golden):
     """maa_ctx_set_concurrency (round 6): told that three contexts are kept in flight, a context takes the short-K contractions'
     tile by least total workgroup time (128 x 64 / 128 x 128 where a launch alone takes 64 x 64) and runs a guided DDIM step on one
