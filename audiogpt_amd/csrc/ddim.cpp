@@ -111,6 +111,8 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
         lane2->prof->detail = ctx.prof->detail;
     }
 
+    // a guided step's halves are the same tensor up to the first cross-attention: computed once (MAA_CFG_SHARED=0: twice)
+    const bool share = cfg && emb_hoist && ctx.tune.cfg_shared;
     // one step: identical launches on identical addresses whatever the step (the index lives on the device)
     auto step_body = [&]() {
         launch_ddim_prepare(ctx, xs, concat ? ccs : nullptr, a.B, nB, per, per_in - per, tab_t, tab_coef, d_step, xin,
@@ -118,14 +120,15 @@ void ddim_sample(Ctx& ctx, UNet& unet, const maa_ddim_args& a, float* d_x) {
         if (lane2) {
             MAA_HIP(hipEventRecord(ctx.ev_fork, ctx.stream));
             MAA_HIP(hipStreamWaitEvent(lane2->stream, ctx.ev_fork, 0));
-            unet.forward(ctx, xin, cur_t, unet.context_ptr, a.B, a.H, a.W, eps, emb_hoist ? cur_emb : nullptr, 0);
+            // (the conditional lane starts from the unconditional lane's layers before the first cross-attention: unet.cpp)
+            unet.forward(ctx, xin, cur_t, unet.context_ptr, a.B, a.H, a.W, eps, emb_hoist ? cur_emb : nullptr, 0, share ? 2 : 0);
             unet.forward(*lane2, xin + (size_t)a.B * per_in, cur_t + a.B, unet.context_ptr, a.B, a.H, a.W, eps + (size_t)a.B * per,
-                         emb_hoist ? cur_emb : nullptr, a.B);
+                         emb_hoist ? cur_emb : nullptr, a.B, share ? 3 : 0);
             MAA_HIP(hipEventRecord(ctx.ev_join, lane2->stream));
             MAA_HIP(hipStreamWaitEvent(ctx.stream, ctx.ev_join, 0));
         } else
             // (one stream: the halves of cat([x] * 2) share every layer before the first cross-attention -- unet.cpp `dup`)
-            unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps, emb_hoist ? cur_emb : nullptr, -1, cfg && emb_hoist);
+            unet.forward(ctx, xin, cur_t, unet.context_ptr, nB, a.H, a.W, eps, emb_hoist ? cur_emb : nullptr, -1, share ? 1 : 0);
         launch_ddim_step(ctx, xin, per, per_in, eps, cfg ? eps + a.B * per : nullptr, a.scale, cur_coef, (long long)a.B * per, xs,
                          a.h_sigmas ? a.d_noise_p : nullptr, a.temperature, a.S, logging ? a.d_log_x : nullptr,
                          logging ? a.d_log_x0 : nullptr, d_step);

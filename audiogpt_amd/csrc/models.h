@@ -19,10 +19,12 @@ public:
     // sample of a DDIM step shares t); null: computed from t (and, I2A, the context) as the reference does per forward
     // batch_off >= 0: this call covers samples [batch_off, batch_off + B) of the batch set_context saw (one lane of a CFG
     // step); x / t / out already point at that sample, the context rows and the cross-attention K/V caches are offset inside
-    // cfg_dup (with emb_row): the batch is cat([x] * 2) of a guided DDIM step -- samples [B/2, B) repeat [0, B/2) and only the
-    // context rows differ: the layers before the first cross-attention run on one half (unet.cpp forward_body)
+    // cfg_share (with emb_row; a guided DDIM step, whose halves are the same tensor before the first cross-attention): 1 = the
+    // batch is cat([x] * 2) on one stream -- samples [B/2, B) repeat [0, B/2) -- and those layers run on one half; 2 / 3 = this
+    // call is the unconditional / conditional lane (batch_off 0 / B): lane 2 leaves those layers' outputs in its workspace,
+    // lane 3 (called after it) starts from them (unet.cpp forward_body)
     void forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
-                 float* out_nchw, const float* emb_row = nullptr, int batch_off = -1, bool cfg_dup = false);
+                 float* out_nchw, const float* emb_row = nullptr, int batch_off = -1, int cfg_share = 0);
     // Linear(SiLU(time_embed(timestep_embedding(t)))) of every ResBlock for `rows` timesteps at once -> [rows, emb_width()]
     // (openaimodel.py:725-726, 218-224): the sampling loop computes its S rows once instead of per step.  Not for the
     // I2A variant, whose embedding also takes the sample's context (custom_openaimodel.py:352-354).

@@ -85,10 +85,29 @@ struct UNet::Impl {
     int kv_rows = 0, kv_len = 0, kv_batch = 0;
     size_t kv_cap_rows = 0;
     DevSlab cfg_context;      // [uncond ; cond] rows of a CFG sample() call
+    // The shared prefix of a guided step run as two lanes (ddim.cpp): the unconditional lane computes the layers before the
+    // first cross-attention as part of its own pass and leaves their four outputs where they are in ITS workspace (share 2);
+    // the conditional lane starts at that cross-attention and reads them (share 3) -- `ready` orders the two streams, the
+    // step's join orders the next step's writes behind the reads.
+    struct Prefix {
+        const float *hs0 = nullptr, *xres = nullptr, *y1 = nullptr, *q = nullptr;
+        int B = 0, H = 0, W = 0;
+        hipEvent_t ready = nullptr;
+    } prefix;
+    int share = 0;            // this forward: 0 whole network, 1 one stream [x ; x] (dup), 2 lane that exports, 3 lane that imports
+
+    // conv_in, then [ResBlock, SpatialTransformer]: the shape the lanes' hand-over is written for (T2A; anything else keeps
+    // the whole evaluation per lane)
+    bool prefix_ok() const {
+        return cfg.use_spatial_transformer && !cfg.add_context_to_emb && input.size() >= 2 && input[0].size() == 1 &&
+               input[0][0].kind == kConv && input[1].size() == 2 && input[1][0].kind == kRes && input[1][1].kind == kST &&
+               !st[input[1][1].idx].blocks.empty();
+    }
 
     ~Impl() {
         for (float* p : kv_cache)
             if (p) (void)hipFree(p);
+        if (prefix.ready) (void)hipEventDestroy(prefix.ready);
     }
 
     // ---- construction ---------------------------------------------------------------------------
@@ -325,13 +344,20 @@ struct UNet::Impl {
 
     // expand: x holds ONE half of a guided step's batch (both halves are equal up to here); the block's first cross-attention
     // is where they part, so everything before it runs on x.B samples and the output has 2 x.B
-    T4 run_st(Ctx& ctx, const STW& s, const T4& x, bool expand = false) {
+    // xp: 2 = this lane leaves y1 / q of the first block for the other lane (allocated outside the block's scratch scope so that
+    // they outlive it), 3 = this lane starts at the first block's cross-attention with the other lane's y1 / q / block input
+    T4 run_st(Ctx& ctx, const STW& s, const T4& x, bool expand = false, int xp = 0) {
         const int HW = x.H * x.W, inner = s.heads * s.dh;
         int B = x.B;                                   // samples of the current tensors
         const int Bo = expand ? 2 * x.B : x.B;
         long long M = (long long)B * HW;
         const long long Mo = (long long)Bo * HW;
         T4 out = alloc_t(ctx, Bo, x.H, x.W, s.ch);
+        float *y1_keep = nullptr, *q_keep = nullptr;
+        if (xp == 2) {
+            y1_keep = ctx.ws.alloc_f((size_t)M * inner);
+            q_keep = ctx.ws.alloc_f((size_t)M * inner);
+        }
         const size_t mk = ctx.ws.mark();
         const float* xres = x.p;                       // proj_out's residual: the block input, for every output sample
         if (expand) {
@@ -339,11 +365,14 @@ struct UNet::Impl {
             launch_dup_half(ctx, x.p, M * s.ch, xd);
             xres = xd;
         }
-        float* xn = ctx.ws.alloc_f((size_t)M * s.ch);
         const bool sp_in = split_for_gemm(ctx, s.ch), sp = split_for_gemm(ctx, inner);
-        launch_groupnorm(ctx, x.p, s.ch, s.ch, nullptr, 0, 0, B, HW, 32, s.ng, s.nb, 1e-6f, 0, xn, sp_in);
-        float* y = ctx.ws.alloc_f((size_t)M * inner);
-        linear_into(ctx, xn, s.ch, M, s.ch, s.proj_in, nullptr, 0, y, inner, 0, 0, sp_in ? M : 0);
+        float* y = nullptr;
+        if (xp != 3) {
+            float* xn = ctx.ws.alloc_f((size_t)M * s.ch);
+            launch_groupnorm(ctx, x.p, s.ch, s.ch, nullptr, 0, 0, B, HW, 32, s.ng, s.nb, 1e-6f, 0, xn, sp_in);
+            y = ctx.ws.alloc_f((size_t)M * inner);
+            linear_into(ctx, xn, s.ch, M, s.ch, s.proj_in, nullptr, 0, y, inner, 0, 0, sp_in ? M : 0);
+        }
         const float scale = 1.0f / std::sqrt((float)s.dh);
         // attention outputs and the GEGLU product feed exactly one projection each: in the bf16 modes they are written
         // as split32 rows, so to_out / ff.net.2 take the LDS-DMA engine with no per-tile conversion
@@ -352,20 +381,34 @@ struct UNet::Impl {
         const int g_sp = !no_osplit && split_for_gemm(ctx, 4 * inner) ? 1 : 0;
         int y_sp = 0;
         for (const STBlockW& b : s.blocks) {
+            const bool first_block = &b == &s.blocks.front();
             float* ln = ctx.ws.alloc_f((size_t)Mo * inner);
             float* o = ctx.ws.alloc_f((size_t)Mo * inner);
-            // x = attn1(norm1(x)) + x      (attention.py:212)
-            launch_layernorm(ctx, y, M, inner, b.ln1g, b.ln1b, 1e-5f, ln, sp);
-            float* qkv = ctx.ws.alloc_f((size_t)M * 3 * inner);
-            linear_into(ctx, ln, inner, M, inner, b.qkv1, nullptr, 0, qkv, 3 * inner, 0, 0, sp ? M : 0);
-            attention_into(ctx, qkv, 3 * inner, s.dh, qkv + inner, 3 * inner, s.dh, qkv + 2 * inner, 3 * inner, s.dh,
-                           B, s.heads, s.dh, HW, HW, scale, o, inner, o_sp);
-            float* y1 = ctx.ws.alloc_f((size_t)M * inner);
-            linear_into(ctx, o, inner, M, inner, b.out1, y, inner, y1, inner, 0, 0, o_sp ? M : 0);
-            // x = attn2(norm2(x), context) + x      (:213)
-            launch_layernorm(ctx, y1, M, inner, b.ln2g, b.ln2b, 1e-5f, ln, sp);
-            float* q = ctx.ws.alloc_f((size_t)M * inner);
-            linear_into(ctx, ln, inner, M, inner, b.q2, nullptr, 0, q, inner, 0, 0, sp ? M : 0);
+            float *y1 = nullptr, *q = nullptr;
+            if (xp == 3 && first_block) {
+                // the other lane computed this far on the same x: its residual stream and queries, read in place
+                y1 = const_cast<float*>(prefix.y1);
+                q = const_cast<float*>(prefix.q);
+            } else {
+                // x = attn1(norm1(x)) + x      (attention.py:212)
+                launch_layernorm(ctx, y, M, inner, b.ln1g, b.ln1b, 1e-5f, ln, sp);
+                float* qkv = ctx.ws.alloc_f((size_t)M * 3 * inner);
+                linear_into(ctx, ln, inner, M, inner, b.qkv1, nullptr, 0, qkv, 3 * inner, 0, 0, sp ? M : 0);
+                attention_into(ctx, qkv, 3 * inner, s.dh, qkv + inner, 3 * inner, s.dh, qkv + 2 * inner, 3 * inner, s.dh,
+                               B, s.heads, s.dh, HW, HW, scale, o, inner, o_sp);
+                y1 = xp == 2 && first_block ? y1_keep : ctx.ws.alloc_f((size_t)M * inner);
+                linear_into(ctx, o, inner, M, inner, b.out1, y, inner, y1, inner, 0, 0, o_sp ? M : 0);
+                // x = attn2(norm2(x), context) + x      (:213)
+                launch_layernorm(ctx, y1, M, inner, b.ln2g, b.ln2b, 1e-5f, ln, sp);
+                q = xp == 2 && first_block ? q_keep : ctx.ws.alloc_f((size_t)M * inner);
+                linear_into(ctx, ln, inner, M, inner, b.q2, nullptr, 0, q, inner, 0, 0, sp ? M : 0);
+                if (xp == 2 && first_block) {
+                    prefix.y1 = y1;
+                    prefix.q = q;
+                    prefix.xres = x.p;
+                    if (!ctx.ws.dry) MAA_HIP(hipEventRecord(prefix.ready, ctx.stream));
+                }
+            }
             if (B != Bo) {      // the halves part here: the same queries and the same residual stream meet two contexts
                 float* qd = ctx.ws.alloc_f((size_t)Mo * inner);
                 float* yd = ctx.ws.alloc_f((size_t)Mo * inner);
@@ -441,7 +484,8 @@ struct UNet::Impl {
                     h = run_res(ctx, res[l.idx], h, x2, emb_out);
                     break;
                 case kST:
-                    h = run_st(ctx, st[l.idx], h, shared && *shared);
+                    h = run_st(ctx, st[l.idx], h, shared && *shared, exporting ? 2 : 0);
+                    exporting = false;
                     if (shared) *shared = false;
                     break;
                 case kAttn:
@@ -491,6 +535,7 @@ struct UNet::Impl {
         launch_silu(ctx, emb, (long long)rows * emb_dim, semb);
         linear_into(ctx, semb, emb_dim, rows, emb_dim, emb_all, nullptr, 0, out, emb_all.Npad);
     }
+    bool exporting = false;      // the next SpatialTransformer run_layers meets hands its prefix over (share 2)
     int emb_ld = 0;      // pitch between the samples' rows of the current forward's emb_out (0: one row for every sample)
     // a forward over samples [batch_off, batch_off + B) of the batch set_context saw (a lane of a CFG step: ddim.cpp); the
     // caller's x / t / out pointers already stand at that sample, the context rows and the K/V caches are offset here
@@ -498,14 +543,18 @@ struct UNet::Impl {
     bool lane = false;
 
     // emb_row != null: the step's ResBlock time-embedding row computed beforehand (UNet::emb_table), shared by all samples
-    // dup: the batch is cat([x] * 2) of a guided step with one time-embedding row for all samples (emb_row)
+    // share_req (guided steps, one time-embedding row for all samples = emb_row): 1 = the batch is cat([x] * 2) on one stream,
+    // 2 / 3 = this call is the unconditional / conditional lane of such a step (the caller runs 2 before 3)
     void forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
-                 float* out_nchw, const float* emb_row = nullptr, bool dup = false) {
+                 float* out_nchw, const float* emb_row = nullptr, int share_req = 0) {
         if (context && batch_off) context += (size_t)batch_off * kv_len * cfg.context_dim;
+        share = 0;
         if (emb_row) {
             emb_ld = 0;
-            forward_body(ctx, x_nchw, B, H, W, out_nchw, emb_row,
-                         dup && ctx.tune.cfg_shared && cfg.use_spatial_transformer && !lane && B % 2 == 0);
+            if (share_req == 1 && cfg.use_spatial_transformer && !lane && B % 2 == 0) share = 1;
+            if ((share_req == 2 || share_req == 3) && lane && prefix_ok()) share = share_req;
+            forward_body(ctx, x_nchw, B, H, W, out_nchw, emb_row);
+            share = 0;
             return;
         }
         float* emb_out = ctx.ws.alloc_f((size_t)B * emb_all.Npad);
@@ -514,12 +563,21 @@ struct UNet::Impl {
         forward_body(ctx, x_nchw, B, H, W, out_nchw, emb_out);
     }
 
-    void forward_body(Ctx& ctx, const float* x_nchw, int B, int H, int W, float* out_nchw, const float* emb_out,
-                      bool dup = false) {
-        const int mc = cfg.model_channels;
-        // dup: samples [B/2, B) repeat samples [0, B/2) (x and the embedding row); only the context rows differ, and the context
+    void forward_body(Ctx& ctx, const float* x_nchw, int B, int H, int W, float* out_nchw, const float* emb_out) {
+        if (share == 3) {
+            forward_rest_of_lane(ctx, B, H, W, out_nchw, emb_out);
+            return;
+        }
+        if (share == 2) {
+            if (!prefix.ready) MAA_HIP(hipEventCreateWithFlags(&prefix.ready, hipEventDisableTiming));
+            prefix.B = B;
+            prefix.H = H;
+            prefix.W = W;
+            exporting = true;
+        }
+        // share 1: samples [B/2, B) repeat samples [0, B/2) (x and the embedding row); only the context rows differ, and the context
         // enters at the first cross-attention -- until then one half is computed and the skip tensors are written twice
-        bool shared = dup;
+        bool shared = share == 1;
         auto both = [&](const T4& t) {
             T4 d = alloc_t(ctx, 2 * t.B, t.H, t.W, t.C);
             launch_dup_half(ctx, t.p, (long long)t.B * t.H * t.W * t.C, d.p);
@@ -531,11 +589,45 @@ struct UNet::Impl {
         for (auto& blk : input) {
             h = run_layers(ctx, blk, h, nullptr, emb_out, &shared);
             hs.push_back(shared ? both(h) : h);
+            if (share == 2 && hs.size() == 1) prefix.hs0 = h.p;      // conv_in's output: the other lane's first skip tensor
         }
+        exporting = false;
         if (shared) {          // (no transformer on the way down: the halves part at the middle block at the latest)
             h = both(h);
             shared = false;
         }
+        finish(ctx, h, hs, B, H, W, out_nchw, emb_out);
+    }
+
+    // The conditional lane of a guided step (share 3): conv_in, the first ResBlock and the first transformer up to attn2's
+    // queries are the unconditional lane's -- same x, same embedding row -- and are read from its workspace.
+    void forward_rest_of_lane(Ctx& ctx, int B, int H, int W, float* out_nchw, const float* emb_out) {
+        MAA_CHECK(prefix.B == B && prefix.H == H && prefix.W == W && prefix.ready, "guided step: the lanes disagree on the shared prefix");
+        if (!ctx.ws.dry) MAA_HIP(hipStreamWaitEvent(ctx.stream, prefix.ready, 0));
+        const STW& s0 = st[input[1][1].idx];
+        auto view = [&](const float* p, int C) {
+            T4 t;
+            t.B = B;
+            t.H = H;
+            t.W = W;
+            t.C = C;
+            t.p = const_cast<float*>(p);
+            return t;
+        };
+        std::vector<T4> hs;
+        hs.push_back(view(prefix.hs0, cfg.model_channels));
+        T4 h = run_st(ctx, s0, view(prefix.xres, s0.ch), false, 3);
+        hs.push_back(h);
+        for (size_t i = 2; i < input.size(); ++i) {
+            h = run_layers(ctx, input[i], h, nullptr, emb_out);
+            hs.push_back(h);
+        }
+        finish(ctx, h, hs, B, H, W, out_nchw, emb_out);
+    }
+
+    // middle block, the way up with the skip tensors, the output head
+    void finish(Ctx& ctx, T4 h, std::vector<T4>& hs, int B, int H, int W, float* out_nchw, const float* emb_out) {
+        const int mc = cfg.model_channels;
         h = run_layers(ctx, middle, h, nullptr, emb_out);
         for (auto& blk : output) {
             T4 skip = hs.back();
@@ -610,13 +702,13 @@ void UNet::set_context_cfg(Ctx& ctx, const float* d_uncond, const float* d_cond,
 }
 
 void UNet::forward(Ctx& ctx, const float* x_nchw, const float* t, const float* context, int B, int H, int W,
-                   float* out_nchw, const float* emb_row, int batch_off, bool cfg_dup) {
+                   float* out_nchw, const float* emb_row, int batch_off, int cfg_share) {
     Impl& m = *impl_;
     PrecisionGuard pg(ctx, m.precision);
     m.lane = batch_off >= 0;
     m.batch_off = m.lane ? batch_off : 0;
     try {
-        run_sized(ctx, [&] { m.forward(ctx, x_nchw, t, context, B, H, W, out_nchw, emb_row, cfg_dup); });
+        run_sized(ctx, [&] { m.forward(ctx, x_nchw, t, context, B, H, W, out_nchw, emb_row, cfg_share); });
     } catch (...) {
         m.batch_off = 0;
         m.lane = false;

@@ -298,25 +298,31 @@ def test_guided_step_shares_the_layers_before_the_first_cross_attention(golden, 
             os.environ["MAA_CFG_SHARED"] = shared
             reload_tuning()
             x = torch.from_numpy(g["x_T"])
-            out[shared, "eager"] = u.ddim_sample(x, steps, a, ap, use_graph=False, **plain).cpu()
-            out[shared, "graph"] = u.ddim_sample(x, steps, a, ap, use_graph=True, **plain).cpu()
-            out[shared, "one"] = u.ddim_sample(x[:1], steps, a, ap, use_graph=True, cond=plain["cond"][:1], uncond=plain["uncond"][:1],
-                                               scale=plain["scale"]).cpu()
-            z, xi, p0 = u.ddim_sample(t("x_T"), steps, a, ap, use_graph=True, **full)
-            out[shared, "full"] = torch.cat([z.cpu().flatten(), xi.cpu().flatten(), p0.cpu().flatten()])
-            c.prof_begin()
-            u.ddim_sample(x, steps[:1], a[:1], ap[:1], use_graph=False, **plain)
-            rows = c.prof_end()
-            flops[shared] = sum(v["flops"] for v in rows.values())
+            for lanes in (False, True):      # one stream: one half computed and duplicated; two lanes: the second starts from the first's prefix
+                c.set_cfg_split(lanes)
+                out[shared, lanes, "eager"] = u.ddim_sample(x, steps, a, ap, use_graph=False, **plain).cpu()
+                out[shared, lanes, "graph"] = u.ddim_sample(x, steps, a, ap, use_graph=True, **plain).cpu()
+                out[shared, lanes, "again"] = u.ddim_sample(x, steps, a, ap, use_graph=True, **plain).cpu()
+                out[shared, lanes, "one"] = u.ddim_sample(x[:1], steps, a, ap, use_graph=True, cond=plain["cond"][:1], uncond=plain["uncond"][:1],
+                                                          scale=plain["scale"]).cpu()
+                z, xi, p0 = u.ddim_sample(t("x_T"), steps, a, ap, use_graph=True, **full)
+                out[shared, lanes, "full"] = torch.cat([z.cpu().flatten(), xi.cpu().flatten(), p0.cpu().flatten()])
+                c.prof_begin()
+                u.ddim_sample(x, steps[:1], a[:1], ap[:1], use_graph=False, **plain)
+                rows = c.prof_end()
+                flops[shared, lanes] = sum(v["flops"] for v in rows.values())
     finally:
         os.environ.pop("MAA_CFG_SHARED", None)
         reload_tuning()
-    assert float(out["0", "eager"].abs().max()) > 0
-    for k in ("eager", "graph", "one", "full"):
-        assert bool(torch.isfinite(out["0", k]).all()) and torch.equal(out["1", k], out["0", k]), k
-    assert torch.equal(out["1", "eager"], out["1", "graph"]) and torch.equal(out["1", "one"], out["1", "graph"][:1])
+        c.set_cfg_split(None)
+    ref = {k: out["0", False, k] for k in ("eager", "graph", "again", "one", "full")}
+    assert float(ref["eager"].abs().max()) > 0 and all(bool(torch.isfinite(v).all()) for v in ref.values())
+    assert torch.equal(ref["eager"], ref["graph"]) and torch.equal(ref["one"], ref["graph"][:1])
+    for (shared, lanes, k), v in out.items():
+        assert torch.equal(v, ref[k]), (shared, lanes, k)
     # conv_in + two 320 -> 320 convolutions + four 320-wide linears + one 780-token self-attention on half the batch
-    assert 0.93 * flops["0"] < flops["1"] < 0.985 * flops["0"], flops
+    for lanes in (False, True):
+        assert 0.93 * flops["0", lanes] < flops["1", lanes] < 0.985 * flops["0", lanes], flops
     u.close()
     c.close()
 
