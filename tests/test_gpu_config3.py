@@ -15,6 +15,7 @@ from audiogpt_amd import weights as WT
 from tests.util import check, record
 
 pytestmark = pytest.mark.gpu
+_ORACLE_ROWS = {}
 
 
 @pytest.mark.parametrize("precision", ["bf16x3", "f32"])
@@ -40,8 +41,9 @@ def test_hifigan_batch64_x1024_matches_reference(golden, precision, name, cfg):
     assert torch.equal(one, wav[row:row + 1]), "a row of the batch of 64 differs from the same item vocoded alone"
     fsd = O.fold_weight_norm(sd)
     for r in (17, 40):
-        with torch.no_grad():
-            o = O.hifigan_forward(fsd, cfg, mel[r:r + 1])
-        check(f"{precision}_{name}_row{r}_vs_oracle", wav[r:r + 1], o, 2e-4)
+        if (name, r) not in _ORACLE_ROWS:          # the CPU oracle's row does not depend on the precision under test: once per model
+            with torch.no_grad():
+                _ORACLE_ROWS[name, r] = O.hifigan_forward(fsd, cfg, mel[r:r + 1])
+        check(f"{precision}_{name}_row{r}_vs_oracle", wav[r:r + 1], _ORACLE_ROWS[name, r], 2e-4)
     v.close()
     ctx.close()
