@@ -657,3 +657,11 @@ def test_librosa_resample_restatement_behaves_like_a_resampler():
     b = resample_poly(x, 160, 441).astype(np.float32)
     assert np.abs(a - b)[1000:15000].max() < 4e-3 * np.abs(b).max()         # 2.5e-3 measured, most of it the 1.003 gain
     assert np.abs(a / 1.0027 - b)[1000:15000].max() < 2e-3 * np.abs(b).max()
+
+
+def test_bench_help_renders():
+    """argparse expands `%` in help strings: a bare one made `python bench.py --help` raise ValueError (round 6)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "--inflight" in r.stdout and "--cfg-split" in r.stdout, r.stderr[-800:]
