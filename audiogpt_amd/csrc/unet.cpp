@@ -549,6 +549,7 @@ struct UNet::Impl {
                  float* out_nchw, const float* emb_row = nullptr, int share_req = 0) {
         if (context && batch_off) context += (size_t)batch_off * kv_len * cfg.context_dim;
         share = 0;
+        exporting = false;      // (a forward that threw half-way must not leave its hand-over armed)
         if (emb_row) {
             emb_ld = 0;
             if (share_req == 1 && cfg.use_spatial_transformer && !lane && B % 2 == 0) share = 1;
